@@ -219,12 +219,15 @@ typedef struct thm_aligner thm_aligner;
  * (src/main.rs:37-43).  `sa` may be NULL (then the library builds it) or a
  * valid suffix array of `text` (checked).  Interval-tree insertion order
  * follows src/index.rs:164-191 (per transcript, genomic exon order) and
- * src/index.rs:208-213 (gene index order).  Immutable and shareable across
- * aligners and threads, like Arc<Index> in src/wrapper.rs:22. */
+ * src/index.rs:208-213 (gene index order).  `name_rank[name_id]` is the rank of
+ * that contig's name in byte-wise string order (filter_overlapping sorts by
+ * ref_name, src/aligner.rs:322-327); NULL means name_id order.  Immutable and
+ * shareable across aligners and threads, like Arc<Index> in src/wrapper.rs:22. */
 int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_ref* refs, uint32_t n_refs,
                                    const thm_tx* txs, uint32_t n_txs, const thm_exon* exons, uint64_t n_exons,
                                    const uint8_t* tx_seq, uint64_t n_tx_seq, const thm_span* genes,
-                                   uint32_t n_genes, const uint32_t* sa, thm_index** out);
+                                   uint32_t n_genes, const uint32_t* name_rank, uint32_t n_names,
+                                   const uint32_t* sa, thm_index** out);
 void thm_index_free(thm_index*);
 /* number of text symbols, suffix-array pointer (host copy, n entries) */
 uint64_t thm_index_text_len(const thm_index*);

@@ -1,0 +1,87 @@
+"""-m gpu: wave primitives and the operator-level SWG kernel against the oracle
+(reference semantics: src/swg.rs:31-240, KATs src/swg.rs:249-317)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from thermite_amd import capi, refdata
+
+from gpu_common import assert_swg_equal, swg_fuzz_problems
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aligner(data_dir):
+    t = refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    ix = capi.Index(t)
+    a = capi.Aligner(ix, dict(capi.DEFAULT_OPTS, min_seed_len=3, min_aln_score=0))
+    yield a
+    a.close()
+    ix.close()
+
+
+def test_wave_primitives(aligner):
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        v = rng.integers(-100000, 100000, 64).astype("<i4")
+        o = aligner.debug_wave_prims(v)
+        assert np.array_equal(o[0], np.maximum.accumulate(v))
+        neg = -858993459
+        ex = np.concatenate([[neg], np.maximum.accumulate(v)[:-1]])
+        assert np.array_equal(o[1], ex)
+        assert np.all(o[2] == v.max()) and np.all(o[3] == v.min())
+        assert np.array_equal(o[4], np.concatenate([[-7], v[:-1]]))
+        assert np.array_equal(o[5], np.concatenate([v[1:], [-9]]))
+
+
+def test_reference_kats(aligner, golden_dir):
+    k = json.load(open(os.path.join(golden_dir, "reference_kats.json")))["swg_extend"]
+    xs = [c["x"].encode() for c in k["cases"]]
+    ys = [c["y"].encode() for c in k["cases"]]
+    xb, xo = refdata.pack_reads(xs)
+    yb, yo = refdata.pack_reads(ys)
+    bw = [c["bw"] for c in k["cases"]]
+    xd = [c["xd"] for c in k["cases"]]
+    alns, ops = aligner.swg_extend_batch(xb, xo, yb, yo, bw, xd, k["max_band_width"])
+    for i, c in enumerate(k["cases"]):
+        a = alns[i]
+        assert (a["score"], a["xend"], a["yend"]) == (c["score"], c["xend"], c["yend"])
+        got = orc.decode_ops(ops[a["ops_off"]: a["ops_off"] + a["ops_len"]])
+        assert got == [tuple(o) if isinstance(o, list) else o for o in c["ops"]]
+
+
+def test_out_of_contract(aligner):
+    xb, xo = refdata.pack_reads([b"ACGT"])
+    with pytest.raises(capi.ThermiteError) as e:
+        aligner.swg_extend_batch(xb, xo, xb, xo, [5], [5], 4)  # bw > max: assert!, src/swg.rs:32
+    assert e.value.code == capi.ERR_OUT_OF_CONTRACT
+    with pytest.raises(capi.ThermiteError) as e:
+        aligner.swg_extend_batch(xb, xo, xb, xo, [3], [2], 4)  # xd < bw: SURVEY A.5
+    assert e.value.code == capi.ERR_OUT_OF_CONTRACT
+
+
+@pytest.mark.parametrize("bw_lo,bw_hi,max_len,n", [(0, 31, 100, 6000), (0, 8, 30, 3000), (32, 63, 150, 1500),
+                                                   (64, 95, 150, 600), (96, 127, 160, 400), (31, 31, 91, 4000)])
+def test_fuzz_vs_oracle(aligner, bw_lo, bw_hi, max_len, n):
+    rng = np.random.default_rng(bw_lo * 1000 + bw_hi)
+    xb, xo, yb, yo, bw, xd = swg_fuzz_problems(rng, n, max_len, bw_lo, bw_hi)
+    aligner.reset_counters()
+    alns, ops = aligner.swg_extend_batch(xb, xo, yb, yo, bw, xd, bw_hi)
+    ref = orc.swg_extend_batch(xb, xo, yb, yo, bw, xd, bw_hi)
+    assert_swg_equal(alns, ops, ref)
+    c = aligner.counters()
+    assert c[9] == ref.counters[9] and c[10] == ref.counters[10] and c[11] == ref.counters[11]
+
+
+def test_empty_inputs(aligner):
+    xs = [b"", b"ACG", b"", b"A"]
+    ys = [b"ACGT", b"", b"", b"A"]
+    xb, xo = refdata.pack_reads(xs)
+    yb, yo = refdata.pack_reads(ys)
+    alns, ops = aligner.swg_extend_batch(xb, xo, yb, yo, [2, 2, 2, 0], [2, 2, 2, 0], 4)
+    ref = orc.swg_extend_batch(xb, xo, yb, yo, [2, 2, 2, 0], [2, 2, 2, 0], 4)
+    assert_swg_equal(alns, ops, ref)

@@ -1,0 +1,410 @@
+// aligner.hip -- host side of the C ABI (include/thermite.h): device upload of
+// the index, the per-aligner stream / scratch, and the batch entry points that
+// stand where aligner::align_read, Index::all_smems and SwgExtend::extend stand
+// in the reference (src/aligner.rs:123, src/index.rs:228, src/swg.rs:31).
+//
+// There is no CPU fallback: without a HIP device every compute entry point
+// fails with THM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "launch.h"
+#include "thermite_internal.h"
+
+namespace thm {
+const char* global_error_cstr();
+}
+using namespace thm;
+
+// ------------------------------------------------------------------ helpers
+struct DBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return (T*)p;
+  }
+};
+
+struct thm_index::DevCopy {
+  int device = -1;
+  DBuf text, sa, lut, refs, name_rank, txs, exons, tx_seq, exon_tree, gene_tree;
+  DeviceIndex view;
+};
+
+static void free_dev_copy(thm_index::DevCopy* d) {
+  if (!d) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  (void)hipSetDevice(d->device);
+  d->text.release();
+  d->sa.release();
+  d->lut.release();
+  d->refs.release();
+  d->name_rank.release();
+  d->txs.release();
+  d->exons.release();
+  d->tx_seq.release();
+  d->exon_tree.release();
+  d->gene_tree.release();
+  (void)hipSetDevice(cur);
+  delete d;
+}
+
+struct thm_aligner {
+  const thm_index* ix = nullptr;
+  thm_index::DevCopy* dix = nullptr;
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  thm_align_opts opts;
+  std::string err;
+
+  // device scratch (grow-only)
+  DBuf d_counters, d_queue, d_fault;
+  DBuf b0, b1, b2, b3, b4, b5, b6, b7, b8;  // operator-level scratch
+  // read-level pipeline
+  DBuf r_bases, r_offsets;
+  uint64_t n_reads = 0, n_bases = 0;
+  uint32_t max_read_len = 0;
+  DBuf s_smems, s_cursor, s_off, s_cnt, s_hits, s_hits_scan, scan_tmp;
+  DBuf e_cands, e_order, e_ops, e_ops_cursor, e_nalns, e_opbytes, e_nalns64, e_aln_off, e_ops_off;
+  DBuf o_alns, o_ops, o_mems;
+  uint64_t smem_cap = 0, cand_ops_cap = 0;
+  bool ran = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float timings[THM_N_TIMINGS] = {0};
+
+  // host results
+  std::vector<uint64_t> h_off;
+  std::vector<thm_aln> h_alns;
+  std::vector<uint8_t> h_ops;
+  std::vector<thm_mem> h_mems;
+  std::vector<thm_swg_aln> h_swg;
+};
+
+static int fail(thm_aligner* a, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (a) a->err = buf;
+  set_global_error(buf);
+  return code;
+}
+
+#define HIPCHK(a, call)                                                                             \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(a, e_ == hipErrorOutOfMemory ? THM_ERR_OOM : THM_ERR_HIP, "%s failed: %s (%s:%d)", \
+                  #call, hipGetErrorString(e_), __FILE__, __LINE__);                                \
+  } while (0)
+
+template <class T>
+static hipError_t upload(DBuf& b, const std::vector<T>& v, hipStream_t s) {
+  size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+  hipError_t e = b.ensure(bytes);
+  if (e != hipSuccess) return e;
+  if (!v.empty()) return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  return hipSuccess;
+}
+
+static int get_dev_copy(thm_aligner* a) {
+  thm_index* ix = const_cast<thm_index*>(a->ix);
+  std::lock_guard<std::mutex> g(*(std::mutex*)ix->dev_mu);
+  if ((int)ix->dev.size() <= a->device) ix->dev.resize(a->device + 1, nullptr);
+  if (!ix->dev[a->device]) {
+    auto* d = new thm_index::DevCopy();
+    d->device = a->device;
+    hipStream_t s = a->stream;
+    hipError_t e = hipSuccess;
+    auto up = [&](auto& buf, const auto& vec) {
+      if (e == hipSuccess) e = upload(buf, vec, s);
+    };
+    up(d->text, ix->text);
+    up(d->sa, ix->sa);
+    up(d->lut, ix->lut);
+    up(d->refs, ix->refs);
+    up(d->name_rank, ix->name_rank);
+    up(d->txs, ix->txs);
+    up(d->exons, ix->exons);
+    up(d->tx_seq, ix->tx_seq);
+    up(d->exon_tree, ix->exon_tree);
+    up(d->gene_tree, ix->gene_tree);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      free_dev_copy(d);
+      return fail(a, e == hipErrorOutOfMemory ? THM_ERR_OOM : THM_ERR_HIP, "index upload failed: %s",
+                  hipGetErrorString(e));
+    }
+    DeviceIndex& v = d->view;
+    v.text = d->text.as<uint8_t>();
+    v.sa = d->sa.as<uint32_t>();
+    v.lut = d->lut.as<LutEntry>();
+    v.refs = d->refs.as<thm_ref>();
+    v.name_rank = d->name_rank.as<uint32_t>();
+    v.txs = d->txs.as<thm_tx>();
+    v.exons = d->exons.as<thm_exon>();
+    v.tx_seq = d->tx_seq.as<uint8_t>();
+    v.exon_tree = d->exon_tree.as<TreeNode>();
+    v.gene_tree = d->gene_tree.as<TreeNode>();
+    v.n = ix->n;
+    v.n_refs = (uint32_t)ix->refs.size();
+    v.n_txs = (uint32_t)ix->txs.size();
+    v.exon_root = ix->exon_root;
+    v.gene_root = ix->gene_root;
+    v.kt = ix->kt;
+    v.pad_ = 0;
+    ix->dev[a->device] = d;
+  }
+  a->dix = ix->dev[a->device];
+  return THM_OK;
+}
+
+static int reset_queue(thm_aligner* a) {
+  HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, 64, a->stream));
+  HIPCHK(a, hipMemsetAsync(a->d_fault.p, 0, 64, a->stream));
+  return THM_OK;
+}
+
+static int grid_blocks(const thm_aligner* a, uint64_t n_items, int waves_per_block, int blocks_per_cu) {
+  uint64_t need = (n_items + waves_per_block - 1) / waves_per_block;
+  uint64_t cap = (uint64_t)a->n_cu * blocks_per_cu;
+  return (int)std::max<uint64_t>(1, std::min(need, cap));
+}
+
+extern "C" {
+
+const char* thm_version(void) { return "thermite_amd 0.1 (gfx950)"; }
+
+int32_t thm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void thm_index_free(thm_index* ix) {
+  if (!ix) return;
+  for (auto* d : ix->dev) free_dev_copy(d);
+  delete (std::mutex*)ix->dev_mu;
+  delete ix;
+}
+
+const char* thm_last_error(const thm_aligner* a) { return a ? a->err.c_str() : global_error_cstr(); }
+
+int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int32_t device_id, thm_aligner** out) {
+  if (!out) return THM_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!ix || !opts) return fail(nullptr, THM_ERR_INVALID_ARG, "thm_aligner_create: null index or opts");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(nullptr, THM_ERR_NO_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, THM_ERR_NO_DEVICE, "device id %d out of range", device_id);
+  thm_aligner* a = new thm_aligner();
+  a->ix = ix;
+  a->device = device_id;
+  a->opts = *opts;
+  auto bail = [&](int code) {
+    thm_aligner_free(a);
+    return code;
+  };
+  if (hipSetDevice(device_id) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipSetDevice failed"));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) a->n_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(nullptr, THM_ERR_HIP, "hipStreamCreate failed"));
+  for (auto& e : a->ev)
+    if (hipEventCreate(&e) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipEventCreate failed"));
+  if (a->d_counters.ensure(THM_N_COUNTERS * 8) != hipSuccess || a->d_queue.ensure(64) != hipSuccess ||
+      a->d_fault.ensure(64) != hipSuccess)
+    return bail(fail(nullptr, THM_ERR_OOM, "scratch allocation failed"));
+  (void)hipMemsetAsync(a->d_counters.p, 0, THM_N_COUNTERS * 8, a->stream);
+  int rc = get_dev_copy(a);
+  if (rc != THM_OK) return bail(rc);
+  rc = thm_aligner_set_opts(a, opts);
+  if (rc != THM_OK) return bail(rc);
+  *out = a;
+  return THM_OK;
+}
+
+void thm_aligner_free(thm_aligner* a) {
+  if (!a) return;
+  (void)hipSetDevice(a->device);
+  if (a->stream) (void)hipStreamSynchronize(a->stream);
+  DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4, &a->b5,
+                 &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->s_smems, &a->s_cursor, &a->s_off,
+                 &a->s_cnt, &a->s_hits, &a->s_hits_scan, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops,
+                 &a->e_ops_cursor, &a->e_nalns, &a->e_opbytes, &a->e_nalns64, &a->e_aln_off, &a->e_ops_off,
+                 &a->o_alns, &a->o_ops, &a->o_mems};
+  for (DBuf* b : all) b->release();
+  for (auto& e : a->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (a->stream) (void)hipStreamDestroy(a->stream);
+  delete a;
+}
+
+int32_t thm_aligner_set_opts(thm_aligner* a, const thm_align_opts* o) {
+  if (!a || !o) return THM_ERR_INVALID_ARG;
+  if (o->min_seed_len < 1 || o->min_seed_len > 65535) return fail(a, THM_ERR_INVALID_ARG, "min_seed_len out of range");
+  if (!(o->min_aln_score_percent >= 0.0f && o->min_aln_score_percent <= 1.0f))
+    return fail(a, THM_ERR_INVALID_ARG, "min_aln_score_percent must be within [0,1] (src/main.rs:46-49)");
+  a->opts = *o;
+  return THM_OK;
+}
+
+void* thm_aligner_stream(thm_aligner* a) { return a ? (void*)a->stream : nullptr; }
+
+int32_t thm_counters_get(thm_aligner* a, uint64_t out[THM_N_COUNTERS]) {
+  if (!a || !out) return THM_ERR_INVALID_ARG;
+  HIPCHK(a, hipSetDevice(a->device));
+  HIPCHK(a, hipMemcpyAsync(out, a->d_counters.p, THM_N_COUNTERS * 8, hipMemcpyDeviceToHost, a->stream));
+  HIPCHK(a, hipStreamSynchronize(a->stream));
+  return THM_OK;
+}
+int32_t thm_counters_reset(thm_aligner* a) {
+  if (!a) return THM_ERR_INVALID_ARG;
+  HIPCHK(a, hipSetDevice(a->device));
+  HIPCHK(a, hipMemsetAsync(a->d_counters.p, 0, THM_N_COUNTERS * 8, a->stream));
+  return THM_OK;
+}
+void* thm_counters_device_ptr(thm_aligner* a) { return a ? a->d_counters.p : nullptr; }
+
+int32_t thm_timings_get(thm_aligner* a, float out[THM_N_TIMINGS]) {
+  if (!a || !out) return THM_ERR_INVALID_ARG;
+  memcpy(out, a->timings, sizeof(a->timings));
+  return THM_OK;
+}
+
+// ------------------------------------------------- SwgExtend::extend batch
+int32_t thm_swg_extend_batch(thm_aligner* a, const uint8_t* x_bases, const uint64_t* x_off, const uint8_t* y_bases,
+                             const uint64_t* y_off, const uint32_t* band_width, const int32_t* x_drop,
+                             uint32_t max_band_width, uint64_t n, thm_swg_view* out) {
+  if (!a || !out || !x_off || !y_off || !band_width || !x_drop) return THM_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  if (n == 0) return THM_OK;
+  if (n >= 0xFFFFFFFFull) return fail(a, THM_ERR_UNSUPPORTED, "more than 2^32-1 problems in one call");
+  HIPCHK(a, hipSetDevice(a->device));
+  uint32_t bw_max = 0, x_max = 0, y_max = 0;
+  std::vector<uint64_t> ops_off(n + 1, 0);
+  for (uint64_t i = 0; i < n; i++) {
+    if (band_width[i] > max_band_width)  // assert!, src/swg.rs:32
+      return fail(a, THM_ERR_OUT_OF_CONTRACT, "problem %llu: band_width %u > max_band_width %u (src/swg.rs:32)",
+                  (unsigned long long)i, band_width[i], max_band_width);
+    if (x_drop[i] < (int64_t)band_width[i])
+      return fail(a, THM_ERR_OUT_OF_CONTRACT, "problem %llu: x_drop < band_width is undefined in the reference",
+                  (unsigned long long)i);
+    uint64_t xl = x_off[i + 1] - x_off[i], yl = y_off[i + 1] - y_off[i];
+    if (x_off[i + 1] < x_off[i] || y_off[i + 1] < y_off[i]) return fail(a, THM_ERR_INVALID_ARG, "offsets not monotone");
+    if (xl > 4000 || band_width[i] > 127) return fail(a, THM_ERR_UNSUPPORTED, "x longer than 4000 or band > 127");
+    uint64_t cols = std::min<uint64_t>(yl, xl + band_width[i] + 1);
+    bw_max = std::max(bw_max, band_width[i]);
+    x_max = std::max<uint32_t>(x_max, (uint32_t)xl);
+    y_max = std::max<uint32_t>(y_max, (uint32_t)cols);
+    ops_off[i + 1] = ops_off[i] + xl + cols + 8;
+  }
+  const int cpl = (int)((2 * bw_max + 1 + 63) / 64);
+  SwgBatchParams p;
+  p.x_cap = (x_max + 15u) & ~15u;
+  p.y_cap = (y_max + 15u) & ~15u;
+  if (p.x_cap == 0) p.x_cap = 16;
+  if (p.y_cap == 0) p.y_cap = 16;
+  if (swg_batch_lds_bytes(p, cpl) > 64 * 1024)
+    return fail(a, THM_ERR_UNSUPPORTED, "band/lengths need %zu bytes of LDS per workgroup (limit 65536)",
+                swg_batch_lds_bytes(p, cpl));
+  const uint64_t xb_n = x_off[n], yb_n = y_off[n], pool = ops_off[n];
+  HIPCHK(a, a->b0.ensure(xb_n + 16));
+  HIPCHK(a, a->b1.ensure((n + 1) * 8));
+  HIPCHK(a, a->b2.ensure(yb_n + 16));
+  HIPCHK(a, a->b3.ensure((n + 1) * 8));
+  HIPCHK(a, a->b4.ensure(n * 4));
+  HIPCHK(a, a->b5.ensure(n * 4));
+  HIPCHK(a, a->b6.ensure((n + 1) * 8));
+  HIPCHK(a, a->b7.ensure(pool + 16));
+  HIPCHK(a, a->b8.ensure(n * sizeof(thm_swg_aln)));
+  hipStream_t s = a->stream;
+  if (xb_n) HIPCHK(a, hipMemcpyAsync(a->b0.p, x_bases, xb_n, hipMemcpyHostToDevice, s));
+  HIPCHK(a, hipMemcpyAsync(a->b1.p, x_off, (n + 1) * 8, hipMemcpyHostToDevice, s));
+  if (yb_n) HIPCHK(a, hipMemcpyAsync(a->b2.p, y_bases, yb_n, hipMemcpyHostToDevice, s));
+  HIPCHK(a, hipMemcpyAsync(a->b3.p, y_off, (n + 1) * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(a, hipMemcpyAsync(a->b4.p, band_width, n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(a, hipMemcpyAsync(a->b5.p, x_drop, n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(a, hipMemcpyAsync(a->b6.p, ops_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+  int rc = reset_queue(a);
+  if (rc != THM_OK) return rc;
+  p.xb = a->b0.as<uint8_t>();
+  p.xo = a->b1.as<uint64_t>();
+  p.yb = a->b2.as<uint8_t>();
+  p.yo = a->b3.as<uint64_t>();
+  p.bw = a->b4.as<uint32_t>();
+  p.xd = a->b5.as<int32_t>();
+  p.ops_off = a->b6.as<uint64_t>();
+  p.ops = a->b7.as<uint8_t>();
+  p.out = a->b8.as<thm_swg_aln>();
+  p.counters = a->d_counters.as<unsigned long long>();
+  p.queue = a->d_queue.as<unsigned int>();
+  p.fault = a->d_fault.as<int>();
+  p.n = n;
+  HIPCHK(a, launch_swg_batch(p, cpl, grid_blocks(a, n, 4, 4), s));
+  std::vector<thm_swg_aln> raw(n);
+  std::vector<uint8_t> pool_h(pool);
+  int fault = 0;
+  HIPCHK(a, hipMemcpyAsync(raw.data(), a->b8.p, n * sizeof(thm_swg_aln), hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipMemcpyAsync(pool_h.data(), a->b7.p, pool, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipMemcpyAsync(&fault, a->d_fault.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipStreamSynchronize(s));
+  if (fault) return fail(a, THM_ERR_INTERNAL, "inconsistent trace in swg_batch_kernel");
+  // canonical layout: op streams back to back in problem order
+  a->h_swg.resize(n);
+  a->h_ops.clear();
+  for (uint64_t i = 0; i < n; i++) {
+    thm_swg_aln r = raw[i];
+    uint64_t off = a->h_ops.size();
+    a->h_ops.insert(a->h_ops.end(), pool_h.begin() + r.ops_off, pool_h.begin() + r.ops_off + r.ops_len);
+    r.ops_off = off;
+    a->h_swg[i] = r;
+  }
+  out->n = n;
+  out->n_op_bytes = a->h_ops.size();
+  out->alns = a->h_swg.data();
+  out->ops = a->h_ops.data();
+  return THM_OK;
+}
+
+// debug hook used by tests/test_gpu_primitives.py: wave scan / shift primitives
+int32_t thm_debug_wave_prims(thm_aligner* a, const int32_t in[64], int32_t out[384]) {
+  if (!a || !in || !out) return THM_ERR_INVALID_ARG;
+  HIPCHK(a, hipSetDevice(a->device));
+  HIPCHK(a, a->b0.ensure(64 * 4));
+  HIPCHK(a, a->b1.ensure(384 * 4));
+  HIPCHK(a, hipMemcpyAsync(a->b0.p, in, 64 * 4, hipMemcpyHostToDevice, a->stream));
+  HIPCHK(a, launch_wave_prims(a->b0.as<int>(), a->b1.as<int>(), a->stream));
+  HIPCHK(a, hipMemcpyAsync(out, a->b1.p, 384 * 4, hipMemcpyDeviceToHost, a->stream));
+  HIPCHK(a, hipStreamSynchronize(a->stream));
+  return THM_OK;
+}
+
+}  // extern "C"

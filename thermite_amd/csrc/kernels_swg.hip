@@ -1,0 +1,131 @@
+// kernels_swg.hip -- operator-level kernel: a batch of independent
+// SwgExtend::extend problems (reference src/swg.rs:31-167), one problem per
+// wavefront, pulled from a device work queue.  This is the surface the
+// reference's known-answer tests pin (src/swg.rs:249-317).
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+#include "swg_device.h"
+
+namespace thm {
+namespace dev {
+
+template <int CPL>
+__global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const uint32_t tr_bytes = (p.y_cap + 1) * CPL * 16;
+  const uint32_t ops_cap = p.x_cap + p.y_cap + 16;
+  const uint32_t per_wave = p.x_cap + p.y_cap + tr_bytes + ops_cap;
+  uint8_t* base = smem + (size_t)wave * per_wave;
+  uint8_t* xs = base;
+  uint8_t* ys = xs + p.x_cap;
+  unsigned long long* trace = (unsigned long long*)(ys + p.y_cap);
+  uint8_t* opsb = (uint8_t*)trace + tr_bytes;
+
+  unsigned long long n_cells = 0, n_cols = 0, n_calls = 0;
+  for (;;) {
+    unsigned idx = 0;
+    if (lane == 0) idx = atomicAdd(p.queue, 1u);
+    idx = (unsigned)bcast_first((int)idx);
+    if (idx >= p.n) break;
+    const uint64_t x0 = p.xo[idx], y0 = p.yo[idx];
+    const int xlen = (int)(p.xo[idx + 1] - x0);
+    const int ylen_full = (int)(p.yo[idx + 1] - y0);
+    const int bw = (int)p.bw[idx];
+    const int xd = p.xd[idx];
+    // only the first xlen+bw+1 columns are reachable
+    const int ylen = min(ylen_full, xlen + bw + 1);
+    for (int t = lane; t < xlen; t += 64) xs[t] = p.xb[x0 + t];
+    for (int t = lane; t < ylen; t += 64) ys[t] = p.yb[y0 + t];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+    SwgResult r = swg_extend_wave<CPL>(xs, xlen, ys, ylen, bw, xd, trace);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // path from the max cell back to the origin, laid out so that it reads forward
+    int nops = swg_traceback_wave<CPL>(trace, r.xend, r.yend, bw, opsb + ops_cap - 1, -1, (int)ops_cap);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (nops < 0) {
+      if (lane == 0) atomicExch(p.fault, 1);
+      nops = 0;
+    }
+    uint8_t* out = p.ops + p.ops_off[idx];
+    const uint8_t* src = opsb + ops_cap - nops;
+    for (int t = lane; t < nops; t += 64) out[t] = src[t];
+    uint32_t total = (uint32_t)nops;
+    if (r.xend < xlen) {  // reference :178-180 Xclip(len - i), last after the reverse
+      if (lane == 0) {
+        const uint32_t clip = (uint32_t)(xlen - r.xend);
+        out[nops] = THM_OP_XCLIP;
+        out[nops + 1] = (uint8_t)(clip);
+        out[nops + 2] = (uint8_t)(clip >> 8);
+        out[nops + 3] = (uint8_t)(clip >> 16);
+        out[nops + 4] = (uint8_t)(clip >> 24);
+      }
+      total += 5;
+    }
+    if (lane == 0) {
+      thm_swg_aln a;
+      a.ops_off = p.ops_off[idx];
+      a.ops_len = total;
+      a.score = r.score;
+      a.xend = (uint32_t)r.xend;
+      a.yend = (uint32_t)r.yend;
+      p.out[idx] = a;
+    }
+    n_cells += r.cells;
+    n_cols += r.cols;
+    n_calls += 1;
+  }
+  if (lane == 0 && n_calls) {
+    atomicAdd(&p.counters[THM_CNT_SWG_CALLS], n_calls);
+    atomicAdd(&p.counters[THM_CNT_DP_CELLS], n_cells);
+    atomicAdd(&p.counters[THM_CNT_DP_COLS], n_cols);
+  }
+}
+
+// wave primitive self-test (checked against numpy on the GPU box)
+__global__ void wave_prims_kernel(const int* in, int* out) {
+  const int l = lane_id();
+  const int v = in[l];
+  out[l] = wave_incl_max_scan(v);
+  out[64 + l] = wave_excl_max_scan(v);
+  out[128 + l] = wave_max(v);
+  out[192 + l] = wave_min(v);
+  out[256 + l] = wave_shr1(v, -7);
+  out[320 + l] = wave_shl1(v, -9);
+}
+
+}  // namespace dev
+
+size_t swg_batch_lds_bytes(const SwgBatchParams& p, int cpl) {
+  const size_t tr = (size_t)(p.y_cap + 1) * cpl * 16;
+  return 4 * ((size_t)p.x_cap + p.y_cap + tr + p.x_cap + p.y_cap + 16);
+}
+
+hipError_t launch_swg_batch(const SwgBatchParams& p, int cpl, int n_blocks, hipStream_t s) {
+  const size_t lds = swg_batch_lds_bytes(p, cpl);
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
+    return hipGetLastError();
+  };
+  switch (cpl) {
+    case 1: return go(dev::swg_batch_kernel<1>);
+    case 2: return go(dev::swg_batch_kernel<2>);
+    case 3: return go(dev::swg_batch_kernel<3>);
+    case 4: return go(dev::swg_batch_kernel<4>);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_wave_prims(const int* in, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(dev::wave_prims_kernel, dim3(1), dim3(64), 0, s, in, out);
+  return hipGetLastError();
+}
+
+}  // namespace thm

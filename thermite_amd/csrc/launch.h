@@ -1,0 +1,134 @@
+// launch.h -- kernel parameter blocks and host-callable launch wrappers.
+#ifndef THERMITE_LAUNCH_H
+#define THERMITE_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+
+#include "thermite_internal.h"
+
+namespace thm {
+
+struct SwgBatchParams {
+  const uint8_t* xb;
+  const uint64_t* xo;
+  const uint8_t* yb;
+  const uint64_t* yo;
+  const uint32_t* bw;
+  const int32_t* xd;
+  const uint64_t* ops_off;  // per problem: start of its slot in the op pool
+  uint8_t* ops;
+  thm_swg_aln* out;
+  unsigned long long* counters;  // THM_N_COUNTERS
+  unsigned int* queue;           // work-queue head, zeroed before launch
+  int* fault;
+  uint64_t n;
+  uint32_t x_cap, y_cap;  // per-wave LDS bytes for x and y (multiples of 16)
+};
+size_t swg_batch_lds_bytes(const SwgBatchParams& p, int cpl);
+hipError_t launch_swg_batch(const SwgBatchParams& p, int cpl, int n_blocks, hipStream_t s);
+hipError_t launch_wave_prims(const int* in, int* out, hipStream_t s);
+
+// ---- read-level pipeline ----
+struct ReadBatch {
+  const uint8_t* bases;     // raw reads (not yet upper-cased), device
+  const uint64_t* offsets;  // [n_reads+1]
+  uint64_t n_reads;
+};
+
+struct SeedParams {
+  DeviceIndex ix;
+  ReadBatch reads;
+  uint32_t min_seed_len;
+  uint32_t max_read_len;       // LDS sizing
+  Smem* smems;                 // pool
+  uint64_t smem_cap;           // pool capacity (entries)
+  unsigned long long* cursor;  // bump allocator head (entries), zeroed before launch
+  uint64_t* read_smem_off;     // [n_reads] first entry of the read's run in the pool
+  uint32_t* read_smem_cnt;     // [n_reads]
+  uint64_t* read_hits;         // [n_reads] total occurrences = sum(hi-lo)
+  unsigned long long* counters;
+  unsigned int* queue;
+  int* fault;  // 1 = smem pool overflow
+};
+size_t seed_lds_bytes(uint32_t max_read_len);
+hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s);
+
+// expand SMEMs into Mem lists (thm_smems_batch)
+struct ExpandParams {
+  DeviceIndex ix;
+  uint64_t n_reads;
+  const Smem* smems;
+  const uint64_t* read_smem_off;
+  const uint32_t* read_smem_cnt;
+  const uint64_t* read_mem_off;  // exclusive prefix sum of read_hits, [n_reads+1]
+  thm_mem* mems;
+};
+hipError_t launch_expand(const ExpandParams& p, hipStream_t s);
+
+// exclusive prefix sum of u64 (n entries -> n+1 entries), single launch for moderate n
+hipError_t launch_exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* block_tmp,
+                                     hipStream_t s);
+size_t scan_tmp_entries(uint64_t n);
+
+// candidate alignment as the extend kernel stores it (device scratch)
+struct Cand {
+  uint64_t ystart, yend, ylen;      // chromosome coords
+  uint64_t tx_ystart, tx_yend, tx_ylen;
+  uint64_t ops_off;                 // into the candidate op pool
+  uint64_t tx_ops_off;
+  int32_t score;
+  uint32_t ref_id;
+  uint32_t xstart, xend;
+  uint32_t ops_len, tx_ops_len;     // bytes (serialised)
+  uint32_t tx_or_gene_idx;
+  int32_t tx_score;
+  uint32_t tx_xstart, tx_xend;
+  uint32_t name_rank;
+  uint8_t strand, aln_type, primary, pad_;
+};
+
+struct ExtendParams {
+  DeviceIndex ix;
+  ReadBatch reads;
+  thm_align_opts opts;
+  const Smem* smems;
+  const uint64_t* read_smem_off;
+  const uint32_t* read_smem_cnt;
+  const uint64_t* read_cand_off;  // exclusive prefix sum of read_hits: the read's slice of cands[]
+  Cand* cands;
+  uint32_t* order;  // [total hits] per-read scratch for the final ordering (indices into the read's slice)
+  uint8_t* cand_ops;
+  uint64_t cand_ops_cap;
+  unsigned long long* ops_cursor;
+  uint32_t* read_n_alns;      // [n_reads] final alignment count
+  uint64_t* read_op_bytes;    // [n_reads] serialised op bytes of the final alignments
+  unsigned long long* counters;
+  unsigned int* queue;
+  int* fault;  // bit 0: op pool overflow, bit 1: internal inconsistency, bit 2: out-of-contract (lift failure)
+  uint32_t max_read_len;
+  uint32_t max_bw;
+  uint32_t max_cols;
+};
+size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
+hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream_t s);
+
+struct CompactParams {
+  uint64_t n_reads;
+  const uint64_t* read_cand_off;
+  const Cand* cands;
+  const uint32_t* order;
+  const uint8_t* cand_ops;
+  const uint32_t* read_n_alns;
+  const uint64_t* read_aln_off;  // exclusive scan of read_n_alns (as u64), [n_reads+1]
+  const uint64_t* read_ops_off;  // exclusive scan of read_op_bytes, [n_reads+1]
+  uint32_t xlen_unused;
+  const uint64_t* read_offsets;  // read lengths
+  thm_aln* alns;
+  uint8_t* ops;
+};
+hipError_t launch_compact(const CompactParams& p, hipStream_t s);
+
+hipError_t launch_widen_u32_to_u64(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t s);
+
+}  // namespace thm
+#endif

@@ -1,0 +1,281 @@
+// swg_device.h -- banded Smith-Waterman-Gotoh extension, one problem per
+// wavefront, for gfx950 (wave64).
+//
+// Semantics: SwgExtend::extend + trace, reference src/swg.rs:31-240 (SURVEY.md
+// Appendix A), bit-exact on the contract x_drop >= band_width.
+//
+// Mapping to the hardware
+//   * the band of one DP column (w = 2*bw+1 slots, reference arrays D/C/R
+//     indexed by band_idx) lives on the lanes: slot b -> lane b / CPL, register
+//     b % CPL (CPL = cells per lane, compile time; w <= 64*CPL);
+//   * columns are walked in order, so the X-drop test (reference :110,:151) is
+//     evaluated exactly where the reference evaluates it;
+//   * the horizontal state C and the diagonal input come from the previous
+//     column: own registers in phase 1 (band anchored at row 0, :75-113), one
+//     DPP wave shift in phase 2 (band slides down, :116-154);
+//   * the vertical gap state R is a serial chain in the reference
+//     (R[i] = max(R[i-1]+ge, D[i-1]+ge+go)).  With gap_open <= 0 it equals
+//     max_{k<i}(D'[k] + go + (i-k)*ge), D' = max(diag, C): a wave-wide exclusive
+//     prefix-max of (D'[k] - k*ge), done with 7 DPP steps (row_shr 1/2/4/8,
+//     row_bcast 15/31, wave_shr 1);
+//   * trace directions are 2 bits per cell: two 64-bit ballots per register
+//     slice per column, stored to LDS by one lane (16*CPL bytes per column);
+//   * the running argmax is kept per lane (first strict improvement, like the
+//     reference's scan order) and reduced across lanes once at the end by
+//     (score desc, column asc, row asc);
+//   * traceback walks the LDS trace from the max cell.
+//
+// Scoring is the aligner's fixed Scoring::from_scores(-1,-1,1,-1)
+// (reference src/aligner.rs:140).
+#ifndef THERMITE_SWG_DEVICE_H
+#define THERMITE_SWG_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+#include "thermite_internal.h"
+
+namespace thm {
+namespace dev {
+
+constexpr int NEG = MIN_SCORE;  // scan identity; never wraps when a few hundred -1s are added
+
+enum : int { OPK_MATCH = 0, OPK_SUBST = 1, OPK_DEL = 2, OPK_INS = 3 };
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+// lane l <- lane l-1 (lane 0 <- fill)
+__device__ __forceinline__ int wave_shr1(int v, int fill) { return dpp_mov<0x138, 0xf>(fill, v); }
+// lane l <- lane l+1 (lane 63 <- fill)
+__device__ __forceinline__ int wave_shl1(int v, int fill) { return dpp_mov<0x130, 0xf>(fill, v); }
+
+// inclusive prefix max over the 64 lanes
+__device__ __forceinline__ int wave_incl_max_scan(int v) {
+  v = max(v, dpp_mov<0x111, 0xf>(NEG, v));  // row_shr:1
+  v = max(v, dpp_mov<0x112, 0xf>(NEG, v));  // row_shr:2
+  v = max(v, dpp_mov<0x114, 0xf>(NEG, v));  // row_shr:4
+  v = max(v, dpp_mov<0x118, 0xf>(NEG, v));  // row_shr:8
+  v = max(v, dpp_mov<0x142, 0xa>(NEG, v));  // row_bcast:15 -> rows 1,3
+  v = max(v, dpp_mov<0x143, 0xc>(NEG, v));  // row_bcast:31 -> rows 2,3
+  return v;
+}
+__device__ __forceinline__ int wave_excl_max_scan(int v) { return wave_incl_max_scan(wave_shr1(v, NEG)); }
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_incl_max_scan(v), 63); }
+__device__ __forceinline__ int wave_min(int v) { return -wave_max(-v); }
+__device__ __forceinline__ int bcast_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct SwgResult {
+  int score, xend, yend;
+  unsigned cells, cols;
+};
+
+// One extension.  xs[0..xlen) / ys[0..ylen) are wave-private LDS byte arrays in
+// DP orientation; trace is wave-private LDS with room for (ylen+1)*CPL*2 u64.
+// Every lane returns the same SwgResult.  Contract: 2*bw+1 <= 64*CPL, xd >= bw.
+template <int CPL>
+__device__ SwgResult swg_extend_wave(const uint8_t* xs, int xlen, const uint8_t* ys, int ylen, int bw, int xd,
+                                     unsigned long long* trace) {
+  SwgResult res;
+  res.score = 0;
+  res.xend = 0;
+  res.yend = 0;
+  res.cells = 0;
+  res.cols = 0;
+  if (xlen == 0 || ylen == 0) return res;  // reference :39-55
+
+  const int lane = lane_id();
+  const int w = 2 * bw + 1;
+  constexpr int ge = GAP_EXTEND, go = GAP_OPEN;
+
+  int Dv[CPL], Cv[CPL];
+  // reference :62-71 leftmost column
+#pragma unroll
+  for (int c = 0; c < CPL; c++) {
+    int b = lane * CPL + c;
+    Dv[c] = (b == 0) ? 0 : b * ge + go;
+    Cv[c] = (b == 0) ? 0 : MIN_SCORE;
+  }
+  int best = 0, best_i = 0, best_j = 0;  // per lane; reference max_score starts at 0
+  int run_max = 0;
+
+  // ---------------- phase 1: band rows 0..w-1 (reference :75-113) ----------------
+  const int p1_end = min(bw, ylen);
+  const int rows1 = min(w, xlen + 1);
+  {
+    int xc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      int b = lane * CPL + c;
+      xc[c] = (b >= 1 && b < rows1) ? (int)xs[b - 1] : 256;
+    }
+    for (int j = 1; j <= p1_end; j++) {
+      const int yc = (int)ys[j - 1];
+      int d[CPL], Cn[CPL], key[CPL];
+      const int d_in = wave_shr1(Dv[CPL - 1], MIN_SCORE);  // D[b-1] of the previous column for register 0
+      int lane_tot = NEG;
+#pragma unroll
+      for (int c = 0; c < CPL; c++) {
+        const int b = lane * CPL + c;
+        const bool valid = b < rows1;
+        Cn[c] = max(Cv[c] + ge, Dv[c] + ge + go);
+        const int dprev = (c == 0) ? d_in : Dv[c - 1];
+        d[c] = (b == 0) ? MIN_SCORE : dprev + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);
+        const int dp = max(d[c], Cn[c]);
+        key[c] = valid ? dp - b * ge : NEG;
+        lane_tot = max(lane_tot, key[c]);
+      }
+      int run = wave_excl_max_scan(lane_tot);
+      int lmax = NEG;
+#pragma unroll
+      for (int c = 0; c < CPL; c++) {
+        const int b = lane * CPL + c;
+        const bool valid = b < rows1;
+        const int R = run + go + b * ge;
+        run = max(run, key[c]);
+        const int dp = max(d[c], Cn[c]);
+        const int Dn = max(dp, R);
+        int dir = (Dn == d[c]) ? ((xc[c] == yc && b > 0) ? OPK_MATCH : OPK_SUBST) : ((Dn == Cn[c]) ? OPK_DEL : OPK_INS);
+        const unsigned long long lo = __ballot((dir & 1) != 0);
+        const unsigned long long hi = __ballot((dir & 2) != 0);
+        if (lane == 0) {
+          trace[((size_t)j * CPL + c) * 2 + 0] = lo;
+          trace[((size_t)j * CPL + c) * 2 + 1] = hi;
+        }
+        if (valid) {
+          if (Dn > best) {
+            best = Dn;
+            best_i = b;
+            best_j = j;
+          }
+          lmax = max(lmax, Dn);
+          Dv[c] = Dn;
+          Cv[c] = Cn[c];
+        }
+      }
+      const int band_max = wave_max(lmax);
+      run_max = max(run_max, band_max);
+      res.cells += (unsigned)rows1;
+      res.cols += 1;
+      // reference :110: with x_drop >= band_width this test can never fire
+      // (SURVEY.md Appendix A.5), so phase 1 always runs to p1_end.
+    }
+  }
+
+  // ---------------- phase 2: band slides down (reference :116-154) ----------------
+  for (int j = bw + 1; j <= ylen; j++) {
+    const int top = j - bw;
+    res.cols += 1;
+    if (top > xlen) break;  // empty row range: band_max = MIN -> X-drop (reference :117-153)
+    const int rows_end = min(top + w, xlen + 1);  // exclusive row bound
+    const int yc = (int)ys[j - 1];
+    int d[CPL], Cn[CPL], key[CPL], xc[CPL], base[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) base[c] = max(Cv[c] + ge, Dv[c] + ge + go);
+    const int c_in = wave_shl1(base[0], MIN_SCORE);  // slot b+1 of the previous column for the last register
+    int lane_tot = NEG;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int b = lane * CPL + c;
+      const int i = top + b;
+      const bool valid = (b < w) && (i < rows_end);
+      xc[c] = valid ? (int)xs[i - 1] : 256;
+      const int cnext = (c == CPL - 1) ? c_in : base[c + 1];
+      Cn[c] = (b >= w - 1) ? MIN_SCORE : cnext;
+      d[c] = Dv[c] + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);
+      const int dp = max(d[c], Cn[c]);
+      key[c] = valid ? dp - b * ge : NEG;
+      lane_tot = max(lane_tot, key[c]);
+    }
+    int run = wave_excl_max_scan(lane_tot);
+    int lmax = NEG;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int b = lane * CPL + c;
+      const int i = top + b;
+      const bool valid = (b < w) && (i < rows_end);
+      const int R = run + go + b * ge;
+      run = max(run, key[c]);
+      const int dp = max(d[c], Cn[c]);
+      const int Dn = max(dp, R);
+      int dir = (Dn == d[c]) ? ((xc[c] == yc) ? OPK_MATCH : OPK_SUBST) : ((Dn == Cn[c]) ? OPK_DEL : OPK_INS);
+      const unsigned long long lo = __ballot((dir & 1) != 0);
+      const unsigned long long hi = __ballot((dir & 2) != 0);
+      if (lane == 0) {
+        trace[((size_t)j * CPL + c) * 2 + 0] = lo;
+        trace[((size_t)j * CPL + c) * 2 + 1] = hi;
+      }
+      if (valid) {
+        if (Dn > best) {
+          best = Dn;
+          best_i = i;
+          best_j = j;
+        }
+        lmax = max(lmax, Dn);
+        Dv[c] = Dn;
+      }
+      Cv[c] = Cn[c];
+    }
+    const int band_max = wave_max(lmax);
+    run_max = max(run_max, band_max);
+    res.cells += (unsigned)(rows_end - top);
+    if (band_max < run_max - xd) break;  // reference :151
+  }
+
+  // ---------------- argmax across lanes: first (j, i) attaining the maximum ----------------
+  const int gmax = wave_max(best);
+  if (gmax > 0) {
+    const int BIG = 0x0fffffff;  // -BIG must stay above the scan identity NEG
+    const int gj = wave_min(best == gmax ? best_j : BIG);
+    const int gi = wave_min((best == gmax && best_j == gj) ? best_i : BIG);
+    res.score = gmax;
+    res.xend = gi;
+    res.yend = gj;
+  }
+  return res;
+}
+
+// Reference trace(), src/swg.rs:170-207, without the leading Xclip.  Walks from
+// (i, j) back to the origin; op k of the walk (k = 0 is the cell at the max) is
+// written to ops[k * stride] with stride = +1 or -1 (so a caller can lay the
+// path out in either direction).  Uniform across the wave; lane 0 stores.
+// Returns the number of ops, or -1 on an inconsistent trace.
+template <int CPL>
+__device__ int swg_traceback_wave(const unsigned long long* trace, int i, int j, int bw, uint8_t* ops, int stride,
+                                  int max_ops) {
+  const int lane = lane_id();
+  int n = 0;
+  while (i > 0 || j > 0) {
+    int op;
+    if (j == 0) {
+      op = OPK_INS;  // column 0 is all Ins (reference :65,:70)
+    } else {
+      const int top = max(j - bw, 0);
+      const int b = i - top;
+      if (b < 0 || b >= 64 * CPL) return -1;
+      const int l = b / CPL, c = b % CPL;
+      const unsigned long long lo = trace[((size_t)j * CPL + c) * 2 + 0];
+      const unsigned long long hi = trace[((size_t)j * CPL + c) * 2 + 1];
+      op = (int)((lo >> l) & 1ull) | ((int)((hi >> l) & 1ull) << 1);
+    }
+    if (n >= max_ops) return -1;
+    if (lane == 0) ops[n * stride] = (uint8_t)op;
+    n++;
+    if (op == OPK_MATCH || op == OPK_SUBST) {
+      i--;
+      j--;
+    } else if (op == OPK_INS) {
+      i--;
+    } else {
+      j--;
+    }
+    if (i < 0 || j < 0) return -1;
+  }
+  return n;
+}
+
+}  // namespace dev
+}  // namespace thm
+#endif

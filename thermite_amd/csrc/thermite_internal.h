@@ -1,0 +1,92 @@
+// thermite_internal.h -- structures shared by the host index builder, the
+// launch code and the HIP kernels.  Not part of the ABI (include/thermite.h is).
+#ifndef THERMITE_INTERNAL_H
+#define THERMITE_INTERNAL_H
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/thermite.h"
+
+namespace thm {
+
+// ---- scoring: Scoring::from_scores(-1, -1, 1, -1), reference src/aligner.rs:140 ----
+constexpr int32_t GAP_OPEN = -1;
+constexpr int32_t GAP_EXTEND = -1;
+constexpr int32_t MATCH_SCORE = 1;
+constexpr int32_t MISMATCH_SCORE = -1;
+// bio::alignment::pairwise::MIN_SCORE (reference src/swg.rs:1)
+constexpr int32_t MIN_SCORE = -858993459;
+
+// ---- flattened interval tree (same shape and visit order as bio's AVL
+// IntervalTree built by the reference, src/index.rs:135,182-183,208-213) ----
+struct TreeNode {
+  uint64_t start, end, max;
+  uint32_t value;
+  int32_t left, right;  // node indices, -1 = none
+  int32_t pad_;
+};
+static_assert(sizeof(TreeNode) == 40, "TreeNode layout");
+
+// k-mer prefix table entry: suffix-array interval of one ACGT-only kt-mer
+struct LutEntry {
+  uint32_t lo, hi;
+};
+
+// device-side view of the index (all pointers in HBM)
+struct DeviceIndex {
+  const uint8_t* text;  // n symbols + 16 bytes of '$' padding
+  const uint32_t* sa;   // n
+  const LutEntry* lut;  // 4^kt
+  const thm_ref* refs;
+  const uint32_t* name_rank;  // per ref
+  const thm_tx* txs;
+  const thm_exon* exons;
+  const uint8_t* tx_seq;
+  const TreeNode* exon_tree;
+  const TreeNode* gene_tree;
+  uint64_t n;
+  uint32_t n_refs, n_txs;
+  int32_t exon_root, gene_root;
+  uint32_t kt;
+  uint32_t pad_;
+};
+
+// one SMEM as the seed kernel emits it: occurrences are sa[lo..hi)
+struct Smem {
+  uint32_t lo, hi;
+  uint16_t qpos, len;
+};
+static_assert(sizeof(Smem) == 12, "Smem layout");
+
+int build_suffix_array(const uint8_t* text, uint64_t n, uint32_t* out);
+bool verify_suffix_array(const uint8_t* text, uint64_t n, const uint32_t* sa);
+
+void set_global_error(const std::string& msg);
+
+}  // namespace thm
+
+// Host index: owns the tables; device copies are created lazily per device.
+struct thm_index {
+  std::vector<uint8_t> text;
+  std::vector<uint32_t> sa;
+  std::vector<thm::LutEntry> lut;
+  uint32_t kt = 0;
+  std::vector<thm_ref> refs;
+  std::vector<uint32_t> name_rank;  // per ref
+  std::vector<thm_tx> txs;
+  std::vector<thm_exon> exons;
+  std::vector<uint8_t> tx_seq;
+  std::vector<thm_span> genes;
+  std::vector<thm::TreeNode> exon_tree, gene_tree;
+  int32_t exon_root = -1, gene_root = -1;
+  uint64_t n = 0;
+  // per-device uploaded copy (guarded by dev_mu)
+  struct DevCopy;
+  std::vector<DevCopy*> dev;  // indexed by device id
+  void* dev_mu = nullptr;     // std::mutex*
+};
+
+#endif
