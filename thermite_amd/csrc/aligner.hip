@@ -15,114 +15,12 @@
 #include <string>
 #include <vector>
 
-#include "launch.h"
-#include "thermite_internal.h"
+#include "aligner_internal.h"
 
 namespace thm {
 const char* global_error_cstr();
 }
 using namespace thm;
-
-// ------------------------------------------------------------------ helpers
-struct DBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  template <class T>
-  T* as() const {
-    return (T*)p;
-  }
-};
-
-struct thm_index::DevCopy {
-  int device = -1;
-  DBuf text, sa, lut, refs, name_rank, txs, exons, tx_seq, exon_tree, gene_tree;
-  DeviceIndex view;
-};
-
-static void free_dev_copy(thm_index::DevCopy* d) {
-  if (!d) return;
-  int cur = 0;
-  (void)hipGetDevice(&cur);
-  (void)hipSetDevice(d->device);
-  d->text.release();
-  d->sa.release();
-  d->lut.release();
-  d->refs.release();
-  d->name_rank.release();
-  d->txs.release();
-  d->exons.release();
-  d->tx_seq.release();
-  d->exon_tree.release();
-  d->gene_tree.release();
-  (void)hipSetDevice(cur);
-  delete d;
-}
-
-struct thm_aligner {
-  const thm_index* ix = nullptr;
-  thm_index::DevCopy* dix = nullptr;
-  int device = 0;
-  int n_cu = 256;
-  hipStream_t stream = nullptr;
-  thm_align_opts opts;
-  std::string err;
-
-  // device scratch (grow-only)
-  DBuf d_counters, d_queue, d_fault;
-  DBuf b0, b1, b2, b3, b4, b5, b6, b7, b8;  // operator-level scratch
-  // read-level pipeline
-  DBuf r_bases, r_offsets;
-  uint64_t n_reads = 0, n_bases = 0;
-  uint32_t max_read_len = 0;
-  DBuf s_smems, s_cursor, s_off, s_cnt, s_hits, s_hits_scan, scan_tmp;
-  DBuf e_cands, e_order, e_ops, e_ops_cursor, e_nalns, e_opbytes, e_nalns64, e_aln_off, e_ops_off;
-  DBuf o_alns, o_ops, o_mems;
-  uint64_t smem_cap = 0, cand_ops_cap = 0;
-  bool ran = false;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  float timings[THM_N_TIMINGS] = {0};
-
-  // host results
-  std::vector<uint64_t> h_off;
-  std::vector<thm_aln> h_alns;
-  std::vector<uint8_t> h_ops;
-  std::vector<thm_mem> h_mems;
-  std::vector<thm_swg_aln> h_swg;
-};
-
-static int fail(thm_aligner* a, int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (a) a->err = buf;
-  set_global_error(buf);
-  return code;
-}
-
-#define HIPCHK(a, call)                                                                             \
-  do {                                                                                              \
-    hipError_t e_ = (call);                                                                         \
-    if (e_ != hipSuccess)                                                                           \
-      return fail(a, e_ == hipErrorOutOfMemory ? THM_ERR_OOM : THM_ERR_HIP, "%s failed: %s (%s:%d)", \
-                  #call, hipGetErrorString(e_), __FILE__, __LINE__);                                \
-  } while (0)
 
 template <class T>
 static hipError_t upload(DBuf& b, const std::vector<T>& v, hipStream_t s) {
@@ -152,6 +50,7 @@ static int get_dev_copy(thm_aligner* a) {
     up(d->name_rank, ix->name_rank);
     up(d->txs, ix->txs);
     up(d->exons, ix->exons);
+    up(d->exon_txoff, ix->exon_txoff);
     up(d->tx_seq, ix->tx_seq);
     up(d->exon_tree, ix->exon_tree);
     up(d->gene_tree, ix->gene_tree);
@@ -169,6 +68,7 @@ static int get_dev_copy(thm_aligner* a) {
     v.name_rank = d->name_rank.as<uint32_t>();
     v.txs = d->txs.as<thm_tx>();
     v.exons = d->exons.as<thm_exon>();
+    v.exon_txoff = d->exon_txoff.as<uint64_t>();
     v.tx_seq = d->tx_seq.as<uint8_t>();
     v.exon_tree = d->exon_tree.as<TreeNode>();
     v.gene_tree = d->gene_tree.as<TreeNode>();
@@ -185,13 +85,13 @@ static int get_dev_copy(thm_aligner* a) {
   return THM_OK;
 }
 
-static int reset_queue(thm_aligner* a) {
+int reset_queue(thm_aligner* a) {
   HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, 64, a->stream));
   HIPCHK(a, hipMemsetAsync(a->d_fault.p, 0, 64, a->stream));
   return THM_OK;
 }
 
-static int grid_blocks(const thm_aligner* a, uint64_t n_items, int waves_per_block, int blocks_per_cu) {
+int grid_blocks(const thm_aligner* a, uint64_t n_items, int waves_per_block, int blocks_per_cu) {
   uint64_t need = (n_items + waves_per_block - 1) / waves_per_block;
   uint64_t cap = (uint64_t)a->n_cu * blocks_per_cu;
   return (int)std::max<uint64_t>(1, std::min(need, cap));
@@ -240,7 +140,7 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
   for (auto& e : a->ev)
     if (hipEventCreate(&e) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipEventCreate failed"));
   if (a->d_counters.ensure(THM_N_COUNTERS * 8) != hipSuccess || a->d_queue.ensure(64) != hipSuccess ||
-      a->d_fault.ensure(64) != hipSuccess)
+      a->d_fault.ensure(64) != hipSuccess || a->d_cursors.ensure(64) != hipSuccess)
     return bail(fail(nullptr, THM_ERR_OOM, "scratch allocation failed"));
   (void)hipMemsetAsync(a->d_counters.p, 0, THM_N_COUNTERS * 8, a->stream);
   int rc = get_dev_copy(a);
@@ -255,11 +155,10 @@ void thm_aligner_free(thm_aligner* a) {
   if (!a) return;
   (void)hipSetDevice(a->device);
   if (a->stream) (void)hipStreamSynchronize(a->stream);
-  DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4, &a->b5,
-                 &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->s_smems, &a->s_cursor, &a->s_off,
-                 &a->s_cnt, &a->s_hits, &a->s_hits_scan, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops,
-                 &a->e_ops_cursor, &a->e_nalns, &a->e_opbytes, &a->e_nalns64, &a->e_aln_off, &a->e_ops_off,
-                 &a->o_alns, &a->o_ops, &a->o_mems};
+  DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->d_cursors, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4,
+                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->s_smems, &a->s_off, &a->s_cnt,
+                 &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops, &a->e_nalns,
+                 &a->e_nalns64, &a->e_opbytes, &a->e_aln_off, &a->e_ops_off, &a->o_alns, &a->o_ops, &a->o_mems};
   for (DBuf* b : all) b->release();
   for (auto& e : a->ev)
     if (e) (void)hipEventDestroy(e);

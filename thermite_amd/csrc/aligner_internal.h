@@ -1,0 +1,116 @@
+// aligner_internal.h -- host-side state shared by aligner.hip and pipeline.hip.
+#ifndef THERMITE_ALIGNER_INTERNAL_H
+#define THERMITE_ALIGNER_INTERNAL_H
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "launch.h"
+#include "thermite_internal.h"
+
+// grow-only device buffer
+struct DBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return (T*)p;
+  }
+};
+
+struct thm_index::DevCopy {
+  int device = -1;
+  DBuf text, sa, lut, refs, name_rank, txs, exons, exon_txoff, tx_seq, exon_tree, gene_tree;
+  thm::DeviceIndex view;
+};
+
+inline void free_dev_copy(thm_index::DevCopy* d) {
+  if (!d) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  (void)hipSetDevice(d->device);
+  DBuf* all[] = {&d->text, &d->sa,         &d->lut,    &d->refs,      &d->name_rank, &d->txs,
+                 &d->exons, &d->exon_txoff, &d->tx_seq, &d->exon_tree, &d->gene_tree};
+  for (DBuf* b : all) b->release();
+  (void)hipSetDevice(cur);
+  delete d;
+}
+
+struct thm_aligner {
+  const thm_index* ix = nullptr;
+  thm_index::DevCopy* dix = nullptr;
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  thm_align_opts opts;
+  std::string err;
+
+  DBuf d_counters, d_queue, d_fault, d_cursors;  // cursors: [0] smem pool head, [1] op pool head (u64 each)
+  DBuf b0, b1, b2, b3, b4, b5, b6, b7, b8;       // operator-level scratch
+
+  // ---- read-level pipeline ----
+  DBuf r_bases, r_offsets;
+  uint64_t n_reads = 0, n_bases = 0;
+  uint32_t max_read_len = 0;
+  bool uploaded = false;
+  // seeds
+  DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp;
+  uint64_t smem_cap = 0;
+  // extension
+  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off;
+  uint64_t cand_cap = 0, cand_ops_cap = 0;
+  // compacted outputs
+  DBuf o_alns, o_ops, o_mems;
+  uint64_t out_alns_cap = 0, out_ops_cap = 0;
+  bool ran = false, synced = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float timings[THM_N_TIMINGS] = {0};
+
+  // host results
+  std::vector<uint64_t> h_off;
+  std::vector<thm_aln> h_alns;
+  std::vector<uint8_t> h_ops;
+  std::vector<thm_mem> h_mems;
+  std::vector<thm_swg_aln> h_swg;
+};
+
+inline int fail(thm_aligner* a, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (a) a->err = buf;
+  thm::set_global_error(buf);
+  return code;
+}
+
+#define HIPCHK(a, call)                                                                             \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(a, e_ == hipErrorOutOfMemory ? THM_ERR_OOM : THM_ERR_HIP, "%s failed: %s (%s:%d)", \
+                  #call, hipGetErrorString(e_), __FILE__, __LINE__);                                \
+  } while (0)
+
+int reset_queue(thm_aligner* a);
+int grid_blocks(const thm_aligner* a, uint64_t n_items, int waves_per_block, int blocks_per_cu);
+#endif

@@ -242,6 +242,14 @@ int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_re
   for (uint32_t i = 0; i < n_refs; i++) ix->name_rank[i] = name_rank ? name_rank[refs[i].name_id] : refs[i].name_id;
   ix->txs.assign(txs, txs + n_txs);
   ix->exons.assign(exons, exons + n_exons);
+  ix->exon_txoff.assign(n_exons, 0);
+  for (uint32_t t = 0; t < n_txs; t++) {
+    uint64_t sum = 0;
+    for (uint32_t e = 0; e < txs[t].n_exons; e++) {
+      ix->exon_txoff[txs[t].exon_begin + e] = sum;
+      sum += exons[txs[t].exon_begin + e].end - exons[txs[t].exon_begin + e].start;
+    }
+  }
   ix->tx_seq.assign(tx_seq, tx_seq + n_tx_seq);
   ix->tx_seq.resize(n_tx_seq + 16, (uint8_t)'$');
   ix->genes.assign(genes, genes + n_genes);

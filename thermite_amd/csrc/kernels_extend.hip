@@ -1,0 +1,854 @@
+// kernels_extend.hip -- the per-read aligner: one read per wavefront.
+//
+// Restates aligner::align_read (reference src/aligner.rs:123-190) and everything
+// below it on the device:
+//     align_seed_hit        src/aligner.rs:198-314
+//     extend_left_right     src/aligner.rs:352-407   (two SwgExtend::extend calls, swg_device.h)
+//     extend_seed_match     src/aligner.rs:410-426
+//     concat_to_chr_aln     src/aligner.rs:429-449
+//     filter_overlapping    src/aligner.rs:317-349
+//     lift_mem_to_tx        src/txome.rs:82-103
+//     lift_tx_to_gx         src/txome.rs:110-160
+//     Index::idx_to_ref     src/index.rs:287-290
+//     Index::seq_slice      src/index.rs:304-323     (a plain slice of the text: both strands are stored)
+//     IntervalTree::find    bio 0.37.1, replayed on the flattened AVL (same visit order)
+//
+// The hits of one read are processed strictly in the reference's order because
+// band_width / x_drop / max_aln_score are loop-carried (src/aligner.rs:143-175).
+// Reads are independent, so the parallelism is: reads over wavefronts, band
+// cells over lanes.  All control flow below is wave-uniform; lane 0 performs the
+// few scalar stores.
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+#include "swg_device.h"
+
+namespace thm {
+namespace dev {
+
+constexpr int MAX_YCLIPS = 64;
+enum : int { FAULT_OPS_POOL = 1, FAULT_INTERNAL = 2, FAULT_CONTRACT = 4 };
+constexpr uint8_t OPK_YMARK = 5;
+
+__device__ __forceinline__ uint8_t sanitize_base_e(uint8_t c) {
+  if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+  return (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') ? c : (uint8_t)0;
+}
+__device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)bcast_first((int)(v >> 32)) << 32) | (unsigned)bcast_first((int)(v & 0xffffffffu));
+}
+__device__ __forceinline__ void wfence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+struct RefInfo {
+  uint64_t start, end, len;
+  uint32_t id;
+  uint32_t name_rank;
+  bool strand;
+};
+// Index::idx_to_ref: refs.partition_point(|x| x.end_idx <= idx)
+__device__ RefInfo idx_to_ref(const DeviceIndex& ix, uint64_t idx) {
+  uint32_t lo = 0, hi = ix.n_refs;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (ix.refs[mid].end_idx <= idx)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo >= ix.n_refs) lo = ix.n_refs - 1;
+  const thm_ref r = ix.refs[lo];
+  RefInfo o;
+  o.start = r.start_idx;
+  o.end = r.end_idx;
+  o.len = r.len;
+  o.id = lo;
+  o.name_rank = ix.name_rank[lo];
+  o.strand = r.strand != 0;
+  return o;
+}
+
+// wave-private LDS carve-up
+template <int CPL>
+struct Wctx {
+  uint8_t* rd;   // sanitised read, zero padded
+  uint8_t* win;  // reference / transcript window
+  unsigned long long* trace;
+  uint8_t* pa;  // three path buffers (op kinds 0..3), rotated by pointer swap
+  uint8_t* pb;
+  uint8_t* pc;
+  uint8_t* lifted;  // path with intron markers
+  uint32_t* ycl;    // intron lengths of `lifted`, in order of appearance
+  uint8_t* ser;     // serialised op stream staging
+  int* stack;       // interval-tree traversal stack
+  int L, opcap, sercap, wcap;
+  unsigned cells, cols, calls;
+  int fault;
+};
+
+struct Path {
+  int score, xstart, xend, nops;
+  long long ystart, yend;  // in the coordinates r / lo_abs were given in
+};
+
+// extend_left_right, reference src/aligner.rs:352-407.  `win` holds ref_seq bytes
+// from absolute coordinate win0; ref_seq itself spans [lo_abs, hi_abs).
+template <int CPL>
+__device__ Path extend_lr(Wctx<CPL>& c, long long win0, long long lo_abs, long long hi_abs, long long r, int q, int len,
+                          int bw, int xd, uint8_t* buf) {
+  const int L = c.L;
+  Path p;
+  // right: x = read[q+len..], y = ref_seq[r+len..]   (:360-362)
+  const int xr = L - (q + len);
+  const long long yr_avail = hi_abs - (r + len);
+  const int yr = (int)min(yr_avail, (long long)(xr + bw + 1));
+  const SwgResult R = swg_extend_wave<CPL>(c.rd + q + len, 1, xr, c.win + (r + len - win0), 1, yr, bw, xd, c.trace);
+  wfence();
+  int nr = swg_traceback_wave<CPL>(c.trace, R.xend, R.yend, bw, buf + c.opcap - 1, -1, c.opcap);
+  wfence();
+  // left: both reversed, y = ref_seq[r.saturating_sub(L+bw)..r]   (:364-375)
+  const int xl = q;
+  const long long rel = r - lo_abs;
+  const long long y0 = lo_abs + (rel > (long long)(L + bw) ? rel - (L + bw) : 0);
+  const int yl = (int)min(r - y0, (long long)(xl + bw + 1));
+  const SwgResult Lt = swg_extend_wave<CPL>(c.rd + q - 1, -1, xl, c.win + (r - 1 - win0), -1, yl, bw, xd, c.trace);
+  wfence();
+  int nl = (nr >= 0) ? swg_traceback_wave<CPL>(c.trace, Lt.xend, Lt.yend, bw, buf, 1, c.opcap - nr) : -1;
+  wfence();
+  c.cells += R.cells + Lt.cells;
+  c.cols += R.cols + Lt.cols;
+  c.calls += 2;
+  if (nr < 0 || nl < 0 || nl + len + nr > c.opcap) {
+    c.fault |= FAULT_INTERNAL;
+    nl = 0;
+    nr = 0;
+  }
+  const int lane = lane_id();
+  // rev(left.ops) ++ Match x len ++ right.ops   (:388-394); the clips are implied by xstart / xend
+  for (int t = lane; t < len; t += 64) buf[nl + t] = OPK_MATCH;
+  for (int t0 = 0; t0 < nr; t0 += 64) {
+    const int t = t0 + lane;
+    uint8_t v = 0;
+    if (t < nr) v = buf[c.opcap - nr + t];
+    wfence();
+    if (t < nr) buf[nl + len + t] = v;
+    wfence();
+  }
+  p.nops = nl + len + nr;
+  p.score = Lt.score + len * MATCH_SCORE + R.score;
+  p.ystart = r - Lt.yend;
+  p.yend = r + len + R.yend;
+  p.xstart = q - Lt.xend;
+  p.xend = q + len + R.xend;
+  return p;
+}
+
+// stage [a, b) of a global byte array into c.win
+template <int CPL>
+__device__ void stage_window(Wctx<CPL>& c, const uint8_t* src, long long a, long long b) {
+  const int n = (int)(b - a);
+  if (n > c.wcap) {
+    c.fault |= FAULT_INTERNAL;
+    return;
+  }
+  for (int t = lane_id(); t < n; t += 64) c.win[t] = src[a + t];
+  wfence();
+}
+
+// serialise a path (kinds 0..3, 5 = intron marker) into c.ser; lane 0 writes.
+// Forward: [Xclip(xstart)] path [Xclip(L-xend)]; reverse mirrors the whole list
+// (concat_to_chr_aln on a reverse-strand Ref, src/aligner.rs:440-447).
+template <int CPL>
+__device__ int serialize(Wctx<CPL>& c, const uint8_t* path, int n, int xstart, int xend, bool reverse, int n_y) {
+  const int first = reverse ? (c.L - xend) : xstart;
+  const int last = reverse ? xstart : (c.L - xend);
+  const int total = n + 4 * n_y + (first > 0 ? 5 : 0) + (last > 0 ? 5 : 0);
+  if (total > c.sercap) {
+    c.fault |= FAULT_INTERNAL;
+    return 0;
+  }
+  if (lane_id() == 0) {
+    uint8_t* o = c.ser;
+    int pos = 0;
+    auto put_clip = [&](uint8_t kind, uint32_t v) {
+      o[pos] = kind;
+      o[pos + 1] = (uint8_t)v;
+      o[pos + 2] = (uint8_t)(v >> 8);
+      o[pos + 3] = (uint8_t)(v >> 16);
+      o[pos + 4] = (uint8_t)(v >> 24);
+      pos += 5;
+    };
+    if (first > 0) put_clip(THM_OP_XCLIP, (uint32_t)first);
+    int yk = reverse ? n_y - 1 : 0;
+    for (int k = 0; k < n; k++) {
+      const uint8_t op = path[reverse ? n - 1 - k : k];
+      if (op == OPK_YMARK) {
+        put_clip(THM_OP_YCLIP, c.ycl[yk]);
+        yk += reverse ? -1 : 1;
+      } else {
+        o[pos++] = op;
+      }
+    }
+    if (last > 0) put_clip(THM_OP_XCLIP, (uint32_t)last);
+  }
+  wfence();
+  return total;
+}
+
+// copy c.ser[0..n) into the global op pool; returns the pool offset
+template <int CPL>
+__device__ unsigned long long emit_ops(Wctx<CPL>& c, const ExtendParams& p, int n) {
+  unsigned long long off = 0;
+  if (lane_id() == 0) off = atomicAdd(p.ops_cursor, (unsigned long long)n);
+  off = bcast64(off);
+  if (off + (unsigned long long)n > p.cand_ops_cap) {
+    c.fault |= FAULT_OPS_POOL;
+    return 0;
+  }
+  for (int t = lane_id(); t < n; t += 64) p.cand_ops[off + t] = c.ser[t];
+  return off;
+}
+
+// lift_tx_to_gx, reference src/txome.rs:110-160, on a path without clips.
+// Returns the number of ops written to c.lifted (with OPK_YMARK markers, lengths
+// in c.ycl), sets gx start/end in concatenated coordinates.
+template <int CPL>
+__device__ int lift_tx_to_gx(Wctx<CPL>& c, const DeviceIndex& ix, const thm_tx& tx, const uint8_t* path, int n,
+                             long long ystart, long long yend, long long& gx_ystart, long long& gx_yend, int& n_y) {
+  const thm_exon* ex = ix.exons + tx.exon_begin;
+  const uint64_t* toff = ix.exon_txoff + tx.exon_begin;
+  const int ne = (int)tx.n_exons;
+  long long i = ystart;
+  // exon where the alignment starts: while exon_sum + len <= i  (:123-126)
+  int lo = 0, hi = ne;  // first e with toff[e] + len(e) > i
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((long long)(toff[mid] + (ex[mid].end - ex[mid].start)) <= i)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  int e = lo;
+  if (e >= ne) {  // index panic in the reference
+    c.fault |= FAULT_CONTRACT;
+    gx_ystart = gx_yend = 0;
+    n_y = 0;
+    return 0;
+  }
+  thm_exon cur = ex[e];
+  long long exon_sum = (long long)toff[e];
+  gx_ystart = (long long)cur.start + (i - exon_sum);
+  int out = 0;
+  n_y = 0;
+  const int lane = lane_id();
+  for (int k = 0; k < n; k++) {
+    if (e + 1 < ne && exon_sum + (long long)(cur.end - cur.start) <= i) {  // :133-141
+      const thm_exon nxt = ex[e + 1];
+      if (n_y >= MAX_YCLIPS || out >= c.opcap + MAX_YCLIPS) {
+        c.fault |= FAULT_INTERNAL;
+        break;
+      }
+      if (lane == 0) {
+        c.lifted[out] = OPK_YMARK;
+        c.ycl[n_y] = (uint32_t)(nxt.start - cur.end);
+      }
+      out++;
+      n_y++;
+      exon_sum += (long long)(cur.end - cur.start);
+      cur = nxt;
+      e++;
+    }
+    const uint8_t op = path[k];
+    if (op == OPK_MATCH || op == OPK_SUBST || op == OPK_DEL) i++;
+    if (lane == 0) c.lifted[out] = op;
+    out++;
+  }
+  if (i != yend) c.fault |= FAULT_CONTRACT;  // assert_eq!(i, tx_aln.yend), :154
+  gx_yend = (long long)cur.start + (i - exon_sum);
+  wfence();
+  return out;
+}
+
+struct Accepted {
+  int score;
+};
+
+template <int CPL>
+__global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  // ---- LDS carve (must match extend_lds_bytes) ----
+  const uint32_t lcap = (p.max_read_len + 31u) & ~15u;
+  const uint32_t wcap = (2u * (p.max_read_len + p.max_bw) + p.max_read_len + 32u) & ~15u;
+  const uint32_t ycols = p.max_read_len + p.max_bw + 2u;
+  const uint32_t trb = (ycols + 1u) * CPL * 16u;
+  const uint32_t opcap = (2u * p.max_read_len + 2u * p.max_bw + 31u) & ~15u;
+  const uint32_t liftcap = opcap + 64u;
+  const uint32_t sercap = (opcap + 64u + 5u * (2u + MAX_YCLIPS) + 15u) & ~15u;
+  const uint32_t per_wave = lcap + wcap + trb + 3u * opcap + liftcap + 4u * MAX_YCLIPS + sercap + 256u;
+  uint8_t* base = smem + (size_t)wave * per_wave;
+  Wctx<CPL> c;
+  c.rd = base;
+  c.win = c.rd + lcap;
+  c.trace = (unsigned long long*)(c.win + wcap);
+  c.pa = (uint8_t*)c.trace + trb;
+  c.pb = c.pa + opcap;
+  c.pc = c.pb + opcap;
+  c.lifted = c.pc + opcap;
+  c.ycl = (uint32_t*)(c.lifted + liftcap);
+  c.ser = (uint8_t*)(c.ycl + MAX_YCLIPS);
+  c.stack = (int*)(c.ser + sercap);
+  c.opcap = (int)opcap;
+  c.sercap = (int)sercap;
+  c.wcap = (int)wcap;
+  c.cells = c.cols = c.calls = 0;
+  c.fault = 0;
+
+  const DeviceIndex& ix = p.ix;
+  unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_type[3] = {0, 0, 0}, k_reads = 0, k_opb = 0;
+  unsigned long long k_cells = 0, k_cols = 0, k_calls = 0;
+
+  for (;;) {
+    unsigned idx = 0;
+    if (lane == 0) idx = atomicAdd(p.queue, 1u);
+    idx = (unsigned)bcast_first((int)idx);
+    if (idx >= p.reads.n_reads) break;
+    const uint64_t r0 = p.reads.offsets[idx];
+    const int L = (int)(p.reads.offsets[idx + 1] - r0);
+    c.L = L;
+    for (int t = lane; t < (int)lcap; t += 64) c.rd[t] = (t < L) ? sanitize_base_e(p.reads.bases[r0 + t]) : (uint8_t)0;
+    wfence();
+
+    // thresholds, reference src/aligner.rs:130-138 (binary32 product, truncation toward zero)
+    const float prod = p.opts.min_aln_score_percent * (float)L;
+    int ms_pct = (prod != prod) ? 0 : (prod >= 2147483648.0f ? 2147483647 : (prod <= -2147483648.0f ? (-2147483647 - 1) : (int)prod));
+    const int min_aln_score = max(ms_pct, p.opts.min_aln_score);
+    int max_aln_score = min_aln_score;
+    int band_width = (min_aln_score < 0) ? 0 : max(L - min_aln_score, 0);
+    int x_drop = band_width;
+    const int range = (int)p.opts.multimap_score_range;
+    const bool intron_mode = p.opts.intron_mode != 0;
+    if (band_width > (int)p.max_bw || 2 * band_width + 1 > 64 * CPL) {
+      c.fault |= FAULT_INTERNAL;
+      band_width = x_drop = 0;
+    }
+
+    const uint64_t cand0 = p.read_cand_off[idx];
+    Cand* cands = p.cands + cand0;
+    uint32_t* order = p.order + 2 * cand0;  // two scratch lists of the read's hit count each
+    const uint64_t n_hits_cap = p.read_cand_off[idx + 1] - cand0;
+    uint32_t n_acc = 0;
+
+    const uint64_t s0 = p.read_smem_off[idx];
+    uint32_t n_sm = p.read_smem_cnt[idx];
+    if (p.read_cand_off[idx + 1] > p.cand_cap) {  // candidate pool too small: the host grows it and reruns
+      c.fault |= FAULT_OPS_POOL;
+      n_sm = 0;
+    }
+    for (uint32_t si = 0; si < n_sm; si++) {
+      const Smem sm = p.smems[s0 + si];
+      const int q = sm.qpos, len = sm.len;
+      uint32_t rr = sm.hi;
+      while (rr > sm.lo) {
+        const uint32_t chunk = min(64u, rr - sm.lo);
+        uint32_t my_sa = 0;
+        if ((uint32_t)lane < chunk) my_sa = ix.sa[rr - 1 - lane];
+        for (uint32_t t = 0; t < chunk; t++) {
+          const long long hr = (long long)(uint32_t)__shfl((int)my_sa, (int)t);
+          // ================= align_seed_hit (src/aligner.rs:198-314) =================
+          const int bw = band_width, xd = x_drop;
+          const RefInfo ref = idx_to_ref(ix, (uint64_t)hr);
+          // genome window (:212-215)
+          const long long rs = (long long)ref.start;
+          const long long seq_start = max((hr > (long long)(L + bw)) ? hr - (L + bw) : 0LL, rs);
+          const long long seq_end = min(hr + len + L + bw, (long long)ref.end - 1);
+          stage_window(c, ix.text, seq_start, seq_end);
+          Path gx = extend_lr(c, seq_start, seq_start, seq_end, hr, q, len, bw, xd, c.pa);
+          uint8_t* gx_path = c.pa;
+
+          // transcripts whose exons overlap the seed (:231-258), IntervalTree::find order
+          bool have_best = false;
+          uint32_t best_tx = 0;
+          Path best;
+          best.score = 0;
+          best.nops = 0;
+          best.xstart = best.xend = 0;
+          best.ystart = best.yend = 0;
+          uint8_t* cur_buf = c.pb;
+          uint8_t* best_buf = c.pc;
+          {
+            const uint64_t qs = (uint64_t)hr, qe = (uint64_t)(hr + len);
+            int sp = 0;
+            if (ix.exon_root >= 0) {
+              if (lane == 0) c.stack[0] = ix.exon_root;
+              sp = 1;
+            }
+            wfence();
+            bool stop = false;
+            while (sp > 0 && !stop) {
+              const int ni = c.stack[--sp];
+              wfence();
+              const TreeNode nd = ix.exon_tree[ni];
+              if (qs < nd.max) {
+                if (nd.left >= 0) {
+                  if (sp >= 62) {
+                    c.fault |= FAULT_INTERNAL;
+                    break;
+                  }
+                  if (lane == 0) c.stack[sp] = nd.left;
+                  sp++;
+                }
+                if (qe > nd.start) {
+                  if (nd.right >= 0) {
+                    if (sp >= 62) {
+                      c.fault |= FAULT_INTERNAL;
+                      break;
+                    }
+                    if (lane == 0) c.stack[sp] = nd.right;
+                    sp++;
+                  }
+                  wfence();
+                  if (qs < nd.end && nd.start < qe) {
+                    // ---- one transcript ----
+                    const uint32_t tx_idx = nd.value;
+                    const thm_tx tx = ix.txs[tx_idx];
+                    // lift_mem_to_tx (src/txome.rs:82-103): first exon in transcript order that intersects
+                    int fe = -1;
+                    for (uint32_t e0 = 0; e0 < tx.n_exons && fe < 0; e0 += 64) {
+                      const uint32_t e = e0 + (uint32_t)lane;
+                      bool hit = false;
+                      if (e < tx.n_exons) {
+                        const thm_exon x = ix.exons[tx.exon_begin + e];
+                        const uint64_t a0 = qs, a1 = qe, b0 = x.start, b1 = x.end;
+                        hit = (a0 >= b0 && a0 < b1) || (b0 >= a0 && b0 < a1);
+                      }
+                      const unsigned long long m = __ballot(hit);
+                      if (m) fe = (int)e0 + __builtin_ctzll(m);
+                    }
+                    if (fe < 0) {  // unreachable!() in the reference
+                      c.fault |= FAULT_CONTRACT;
+                    } else {
+                      const thm_exon x = ix.exons[tx.exon_begin + fe];
+                      const long long exon_sum = (long long)ix.exon_txoff[tx.exon_begin + fe];
+                      const long long xs = (long long)x.start, xe = (long long)x.end;
+                      long long t_r = ((hr > xs) ? hr - xs : 0) + exon_sum;
+                      const long long start_offset = (xs > hr) ? xs - hr : 0;
+                      const long long t_end = min(hr + len, xe) - xs + exon_sum;
+                      int t_q = q + (int)start_offset;
+                      int t_len = (int)(t_end - t_r);
+                      const long long tlen = (long long)tx.seq_len;
+                      // window of the transcript around the lifted seed
+                      const long long ws = (t_r > (long long)(L + bw)) ? t_r - (L + bw) : 0;
+                      const long long we = min(tlen, t_r + t_len + L + bw + 1);
+                      stage_window(c, ix.tx_seq + tx.seq_off, ws, we);
+                      // extend_seed_match (src/aligner.rs:410-426)
+                      {
+                        int ext = 0;
+                        bool done = false;
+                        while (!done) {
+                          const int tt = ext + lane;
+                          const long long rp = t_r + t_len + tt;
+                          const int qp = t_q + t_len + tt;
+                          const bool ok = (rp < tlen) && (qp < L) && (c.win[rp - ws] == c.rd[qp]);
+                          const unsigned long long bad = __ballot(!ok);
+                          if (bad) {
+                            ext += __builtin_ctzll(bad);
+                            done = true;
+                          } else {
+                            ext += 64;
+                          }
+                        }
+                        t_len += ext;
+                        ext = 0;
+                        done = false;
+                        while (!done) {
+                          const int tt = ext + lane + 1;
+                          const long long rp = t_r - tt;
+                          const int qp = t_q - tt;
+                          const bool ok = (rp >= 0) && (qp >= 0) && (c.win[rp - ws] == c.rd[qp]);
+                          const unsigned long long bad = __ballot(!ok);
+                          if (bad) {
+                            ext += __builtin_ctzll(bad);
+                            done = true;
+                          } else {
+                            ext += 64;
+                          }
+                        }
+                        t_r -= ext;
+                        t_q -= ext;
+                        t_len += ext;
+                      }
+                      Path ta = extend_lr(c, ws, 0, tlen, t_r, t_q, t_len, bw, xd, cur_buf);
+                      if (!have_best || ta.score > best.score) {  // strictly better (:249)
+                        have_best = true;
+                        best_tx = tx_idx;
+                        best = ta;
+                        uint8_t* tmp = cur_buf;
+                        cur_buf = best_buf;
+                        best_buf = tmp;
+                      }
+                      if (ta.score >= L * MATCH_SCORE) stop = true;  // cannot beat an exact match (:253-257)
+                    }
+                  }
+                }
+              }
+            }
+          }
+
+          // ---- exonic vs unspliced (:263-313) ----
+          int aln_type;
+          uint32_t type_idx = THM_NO_IDX;
+          long long cy0, cy1;  // concatenated coordinates of the genome alignment
+          const uint8_t* g_path;
+          int g_n, g_ny = 0;
+          int sc, xs_, xe_;
+          if (have_best && best.score >= gx.score) {
+            const thm_tx tx = ix.txs[best_tx];
+            g_n = lift_tx_to_gx(c, ix, tx, best_buf, best.nops, best.ystart, best.yend, cy0, cy1, g_ny);
+            g_path = c.lifted;
+            aln_type = THM_ALN_EXONIC;
+            type_idx = best_tx;
+            sc = best.score;
+            xs_ = best.xstart;
+            xe_ = best.xend;
+          } else {
+            cy0 = gx.ystart;
+            cy1 = gx.yend;
+            g_path = gx_path;
+            g_n = gx.nops;
+            sc = gx.score;
+            xs_ = gx.xstart;
+            xe_ = gx.xend;
+            aln_type = THM_ALN_INTERGENIC;
+            if (intron_mode) {
+              // first interval gene_intervals.find yields (:283-288, :306)
+              const uint64_t qs = (uint64_t)cy0, qe = (uint64_t)cy1;
+              int sp = 0;
+              if (ix.gene_root >= 0) {
+                if (lane == 0) c.stack[0] = ix.gene_root;
+                sp = 1;
+              }
+              wfence();
+              while (sp > 0) {
+                const int ni = c.stack[--sp];
+                wfence();
+                const TreeNode nd = ix.gene_tree[ni];
+                if (qs < nd.max) {
+                  if (nd.left >= 0 && sp < 62) {
+                    if (lane == 0) c.stack[sp] = nd.left;
+                    sp++;
+                  }
+                  if (qe > nd.start) {
+                    if (nd.right >= 0 && sp < 62) {
+                      if (lane == 0) c.stack[sp] = nd.right;
+                      sp++;
+                    }
+                    wfence();
+                    if (qs < nd.end && nd.start < qe) {
+                      aln_type = THM_ALN_INTRONIC;
+                      type_idx = nd.value;
+                      break;
+                    }
+                  }
+                }
+                wfence();
+              }
+            }
+          }
+          // ================= back in align_read's loop (:146-174) =================
+          bool accept = intron_mode || aln_type == THM_ALN_EXONIC;
+          if (sc < p.opts.min_aln_score || sc < min_aln_score || sc < max_aln_score - range) accept = false;
+          if (accept) {
+            // concat_to_chr_aln (:429-449)
+            const RefInfo cref = idx_to_ref(ix, (uint64_t)cy0);
+            uint64_t ch0, ch1;
+            bool rev;
+            if (cref.strand) {
+              ch0 = (uint64_t)cy0 - cref.start;
+              ch1 = (uint64_t)cy1 - cref.start;
+              rev = false;
+            } else {
+              ch0 = cref.len - ((uint64_t)cy1 - cref.start);
+              ch1 = cref.len - ((uint64_t)cy0 - cref.start);
+              rev = true;
+            }
+            const int nb = serialize(c, g_path, g_n, xs_, xe_, rev, g_ny);
+            const unsigned long long off = emit_ops(c, p, nb);
+            unsigned long long toff2 = 0;
+            int tnb = 0;
+            if (aln_type == THM_ALN_EXONIC) {
+              tnb = serialize(c, best_buf, best.nops, best.xstart, best.xend, false, 0);
+              toff2 = emit_ops(c, p, tnb);
+            }
+            if (n_acc >= n_hits_cap) {
+              c.fault |= FAULT_INTERNAL;
+            } else if (lane == 0) {
+              Cand cd;
+              cd.ystart = ch0;
+              cd.yend = ch1;
+              cd.ylen = cref.len;
+              cd.ops_off = off;
+              cd.ops_len = (uint32_t)nb;
+              cd.score = sc;
+              cd.ref_id = ref.id;
+              cd.xstart = (uint32_t)xs_;
+              cd.xend = (uint32_t)xe_;
+              cd.tx_or_gene_idx = type_idx;
+              cd.name_rank = ref.name_rank;
+              cd.strand = ref.strand ? 1 : 0;
+              cd.aln_type = (uint8_t)aln_type;
+              cd.primary = 0;
+              cd.pad_ = 0;
+              cd.tx_ystart = cd.tx_yend = cd.tx_ylen = 0;
+              cd.tx_ops_off = 0;
+              cd.tx_ops_len = 0;
+              cd.tx_score = 0;
+              cd.tx_xstart = cd.tx_xend = 0;
+              if (aln_type == THM_ALN_EXONIC) {
+                cd.tx_ystart = (uint64_t)best.ystart;
+                cd.tx_yend = (uint64_t)best.yend;
+                cd.tx_ylen = ix.txs[best_tx].seq_len;
+                cd.tx_ops_off = toff2;
+                cd.tx_ops_len = (uint32_t)tnb;
+                cd.tx_score = best.score;
+                cd.tx_xstart = (uint32_t)best.xstart;
+                cd.tx_xend = (uint32_t)best.xend;
+              }
+              cands[n_acc] = cd;
+            }
+            n_acc++;
+            // narrow the band (:162-172)
+            const int lim = max(L + range - sc, 0);
+            band_width = min(band_width, lim);
+            x_drop = min(x_drop, lim);
+            max_aln_score = max(max_aln_score, sc);
+          }
+        }
+        rr -= chunk;
+      }
+    }
+    __threadfence_block();
+
+    // ============ retain / filter_overlapping / sort / primary (:177-187) ============
+    uint32_t* la = order;               // list A
+    uint32_t* lb = order + n_hits_cap;  // list B
+    uint32_t m = 0;
+    // retain(score >= max - range), keeps order
+    for (uint32_t t0 = 0; t0 < n_acc; t0 += 64) {
+      const uint32_t t = t0 + lane;
+      const bool keep = (t < n_acc) && (cands[t].score >= max_aln_score - range);
+      const unsigned long long mk = __ballot(keep);
+      if (keep) la[m + __popcll(mk & ((1ull << lane) - 1ull))] = t;
+      m += (uint32_t)__popcll(mk);
+    }
+    __threadfence_block();
+    uint32_t nres = 0;
+    if (m == 1) {
+      nres = 1;
+    } else if (m > 1) {
+      // stable sort by (ref_name, strand, ystart) (:322-327): rank sort la -> lb
+      for (uint32_t t0 = 0; t0 < m; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        if (t < m) {
+          const Cand a = cands[la[t]];
+          uint32_t rank = 0;
+          for (uint32_t u = 0; u < m; u++) {
+            const Cand b = cands[la[u]];
+            bool less;
+            if (b.name_rank != a.name_rank)
+              less = b.name_rank < a.name_rank;
+            else if (b.strand != a.strand)
+              less = b.strand < a.strand;
+            else if (b.ystart != a.ystart)
+              less = b.ystart < a.ystart;
+            else
+              less = u < t;
+            rank += less ? 1u : 0u;
+          }
+          lb[rank] = la[t];
+        }
+      }
+      __threadfence_block();
+      // sweep (:329-346): result into la
+      uint64_t max_end = 0;
+      uint32_t l_rank = 0, l_strand = 0;
+      int l_score = 0;
+      uint64_t l_yend = 0;
+      for (uint32_t s = 0; s < m; s++) {
+        const uint32_t ci = lb[s];
+        const Cand a = cands[ci];
+        if (nres == 0 || a.ystart >= max_end || a.name_rank != l_rank || a.strand != l_strand) {
+          max_end = a.yend;
+          if (lane == 0) la[nres] = ci;
+          nres++;
+          l_rank = a.name_rank;
+          l_strand = a.strand;
+          l_score = a.score;
+          l_yend = a.yend;
+        } else {
+          if (a.score > l_score) {
+            if (lane == 0) la[nres - 1] = ci;
+            l_score = a.score;
+            l_yend = a.yend;
+          }
+          max_end = max(max_end, l_yend);
+        }
+      }
+      __threadfence_block();
+      // stable sort by -score (:183): rank sort la -> lb, then copy back
+      for (uint32_t t0 = 0; t0 < nres; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        if (t < nres) {
+          const int sa_ = cands[la[t]].score;
+          uint32_t rank = 0;
+          for (uint32_t u = 0; u < nres; u++) {
+            const int sb = cands[la[u]].score;
+            rank += (sb > sa_ || (sb == sa_ && u < t)) ? 1u : 0u;
+          }
+          lb[rank] = la[t];
+        }
+      }
+      __threadfence_block();
+      for (uint32_t t = lane; t < nres; t += 64) la[t] = lb[t];
+      __threadfence_block();
+    }
+    // per-read totals
+    unsigned long long opb = 0;
+    for (uint32_t t = lane; t < nres; t += 64) {
+      const Cand a = cands[la[t]];
+      opb += a.ops_len + a.tx_ops_len;
+      k_type[0] += (a.aln_type == THM_ALN_EXONIC);
+      k_type[1] += (a.aln_type == THM_ALN_INTRONIC);
+      k_type[2] += (a.aln_type == THM_ALN_INTERGENIC);
+    }
+    for (int o = 32; o > 0; o >>= 1) opb += __shfl_xor(opb, o);
+    if (lane == 0) {
+      p.read_n_alns[idx] = nres;
+      p.read_op_bytes[idx] = opb;
+    }
+    k_reads++;
+    if (nres)
+      k_aligned++;
+    else
+      k_unmapped++;
+    k_alns += nres;
+    k_opb += opb;
+    k_cells += c.cells;
+    k_cols += c.cols;
+    k_calls += c.calls;
+    c.cells = c.cols = c.calls = 0;
+    wfence();
+  }
+  for (int t = 0; t < 3; t++)
+    for (int o = 32; o > 0; o >>= 1) k_type[t] += __shfl_xor(k_type[t], o);
+  if (lane == 0) {
+    if (c.fault) atomicOr(p.fault, c.fault);
+    if (k_reads) {
+      atomicAdd(&p.counters[THM_CNT_READS], k_reads);
+      atomicAdd(&p.counters[THM_CNT_ALIGNED], k_aligned);
+      atomicAdd(&p.counters[THM_CNT_UNMAPPED], k_unmapped);
+      atomicAdd(&p.counters[THM_CNT_ALNS], k_alns);
+      atomicAdd(&p.counters[THM_CNT_EXONIC], k_type[0]);
+      atomicAdd(&p.counters[THM_CNT_INTRONIC], k_type[1]);
+      atomicAdd(&p.counters[THM_CNT_INTERGENIC], k_type[2]);
+      atomicAdd(&p.counters[THM_CNT_SWG_CALLS], k_calls);
+      atomicAdd(&p.counters[THM_CNT_DP_CELLS], k_cells);
+      atomicAdd(&p.counters[THM_CNT_DP_COLS], k_cols);
+      atomicAdd(&p.counters[THM_CNT_OP_BYTES], k_opb);
+    }
+  }
+}
+
+// final layout: alignments of read r at alns[read_aln_off[r]..], op streams back
+// to back in the same order (gx ops, then tx ops of an exonic alignment)
+__global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
+  const int lane = lane_id();
+  const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.n_reads) return;
+  const uint32_t n = p.read_n_alns[r];
+  if (n == 0) return;
+  const uint64_t cand0 = p.read_cand_off[r];
+  const Cand* cands = p.cands + cand0;
+  const uint32_t* la = p.order + 2 * cand0;
+  const uint32_t xlen = (uint32_t)(p.read_offsets[r + 1] - p.read_offsets[r]);
+  uint64_t o = p.read_ops_off[r];
+  const uint64_t a0 = p.read_aln_off[r];
+  for (uint32_t t = 0; t < n; t++) {
+    const Cand cd = cands[la[t]];
+    for (uint32_t b = lane; b < cd.ops_len; b += 64) p.ops[o + b] = p.cand_ops[cd.ops_off + b];
+    const uint64_t go = o;
+    o += cd.ops_len;
+    for (uint32_t b = lane; b < cd.tx_ops_len; b += 64) p.ops[o + b] = p.cand_ops[cd.tx_ops_off + b];
+    const uint64_t to = o;
+    o += cd.tx_ops_len;
+    if (lane == 0) {
+      thm_aln a;
+      a.ystart = cd.ystart;
+      a.yend = cd.yend;
+      a.ylen = cd.ylen;
+      a.ops_off = go;
+      a.tx_ystart = cd.tx_ystart;
+      a.tx_yend = cd.tx_yend;
+      a.tx_ylen = cd.tx_ylen;
+      a.tx_ops_off = (cd.aln_type == THM_ALN_EXONIC) ? to : 0;
+      a.score = cd.score;
+      a.ref_id = cd.ref_id;
+      a.xstart = cd.xstart;
+      a.xend = cd.xend;
+      a.xlen = xlen;
+      a.ops_len = cd.ops_len;
+      a.tx_or_gene_idx = cd.tx_or_gene_idx;
+      a.tx_score = cd.tx_score;
+      a.tx_xstart = cd.tx_xstart;
+      a.tx_xend = cd.tx_xend;
+      a.tx_ops_len = cd.tx_ops_len;
+      a.strand = cd.strand;
+      a.primary = (t == 0) ? 1 : 0;  // src/aligner.rs:185-187
+      a.aln_type = cd.aln_type;
+      a.pad_ = 0;
+      p.alns[a0 + t] = a;
+    }
+  }
+}
+
+}  // namespace dev
+
+size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
+  const uint32_t lcap = (max_read_len + 31u) & ~15u;
+  const uint32_t wcap = (2u * (max_read_len + max_bw) + max_read_len + 32u) & ~15u;
+  const uint32_t ycols = max_read_len + max_bw + 2u;
+  const uint32_t trb = (ycols + 1u) * cpl * 16u;
+  const uint32_t opcap = (2u * max_read_len + 2u * max_bw + 31u) & ~15u;
+  const uint32_t liftcap = opcap + 64u;
+  const uint32_t sercap = (opcap + 64u + 5u * (2u + dev::MAX_YCLIPS) + 15u) & ~15u;
+  const uint32_t per_wave = lcap + wcap + trb + 3u * opcap + liftcap + 4u * dev::MAX_YCLIPS + sercap + 256u;
+  return 4 * (size_t)per_wave;
+}
+
+hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream_t s) {
+  const size_t lds = extend_lds_bytes(p.max_read_len, p.max_bw, cpl);
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
+    return hipGetLastError();
+  };
+  switch (cpl) {
+    case 1: return go(dev::extend_kernel<1>);
+    case 2: return go(dev::extend_kernel<2>);
+    case 3: return go(dev::extend_kernel<3>);
+    case 4: return go(dev::extend_kernel<4>);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_compact(const CompactParams& p, hipStream_t s) {
+  const unsigned blocks = (unsigned)((p.n_reads + 3) / 4);
+  if (blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::compact_kernel, dim3(blocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace thm

@@ -1,0 +1,287 @@
+// kernels_seed.hip -- seed lookup: all supermaximal exact matches (SMEMs) of
+// length >= min_seed_len of each read against the both-strand text, i.e. the
+// result of Index::all_smems (reference src/index.rs:228-255), one read per
+// wavefront.
+//
+// The reference walks an FMD index (bio 0.37.1, ~2L dependent Occ lookups per
+// read).  Here every read position is searched independently by one lane:
+//     kt-mer prefix table  ->  suffix-array interval  ->  refine by binary search
+//     on (sa, text)  ->  once one suffix is left, 8-byte compares along the text.
+// That yields the matching statistics MS[i]; position i starts an SMEM iff
+// i + MS[i] > (i-1) + MS[i-1], and only matches of
+// length >= k are needed, so positions whose kt-mer is absent stop after one
+// table probe.  The SMEMs are then put in the order the reference's
+// `mems.sort_by_key(len); mems.reverse()` produces:
+// length descending, ties by reverse emission order of FMDIndex::all_smems;
+// occurrences of one SMEM are sa[hi-1], ..., sa[lo] (descending rank).
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+#include "swg_device.h"
+
+namespace thm {
+namespace dev {
+
+__device__ __forceinline__ int base_code(uint8_t c) {
+  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+}
+// upper-case (reference src/aligner.rs:125) and map every byte that cannot
+// occur in the text to 0, which matches nothing (text symbols are $ACGNT and a
+// read never legitimately holds '$')
+__device__ __forceinline__ uint8_t sanitize_base(uint8_t c) {
+  if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+  return (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') ? c : (uint8_t)0;
+}
+__device__ __forceinline__ uint64_t load8_global(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);  // one global_load_dwordx2; gfx950 serves unaligned global loads
+  return v;
+}
+// 8 bytes from an LDS byte array at any offset (two aligned reads + funnel shift)
+__device__ __forceinline__ uint64_t load8_lds(const uint8_t* base16, int off) {
+  const uint64_t* q = (const uint64_t*)(base16 + (off & ~7));
+  const unsigned sh = (unsigned)(off & 7) * 8u;
+  const uint64_t w0 = q[0], w1 = q[1];
+  return sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
+}
+
+// longest match of rd[pos..L) in the text: length d and suffix-array interval
+__device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int pos, int k, int& out_d, uint32_t& out_lo,
+                          uint32_t& out_hi) {
+  uint32_t lo = 0, hi = (uint32_t)ix.n;
+  int d = 0;
+  const int kt = (int)ix.kt;
+  if (kt <= k) {
+    uint32_t code = 0;
+    bool acgt = true;
+    for (int t = 0; t < kt; t++) {
+      const int c = base_code(rd[pos + t]);
+      acgt = acgt && (c >= 0);
+      code = (code << 2) | (uint32_t)(c & 3);
+    }
+    if (acgt) {
+      const LutEntry e = ix.lut[code];
+      lo = e.lo;
+      hi = e.hi;
+      d = kt;
+    }
+  }
+  while (lo < hi && pos + d < L) {
+    if (hi - lo == 1) {
+      // a single suffix left: compare along the text 8 bytes at a time
+      const uint8_t* tp = ix.text + ix.sa[lo];
+      for (;;) {
+        const int rem = L - (pos + d);
+        if (rem <= 0) break;
+        const uint64_t x = load8_global(tp + d) ^ load8_lds(rd, pos + d);
+        int m = x ? (__builtin_ctzll(x) >> 3) : 8;
+        m = min(m, rem);
+        d += m;
+        if (m < 8) break;
+      }
+      break;
+    }
+    const uint8_t c = rd[pos + d];
+    uint32_t a = lo, b = hi;
+    while (a < b) {
+      const uint32_t m = a + ((b - a) >> 1);
+      if (ix.text[(uint64_t)ix.sa[m] + d] < c)
+        a = m + 1;
+      else
+        b = m;
+    }
+    const uint32_t nlo = a;
+    b = hi;
+    while (a < b) {
+      const uint32_t m = a + ((b - a) >> 1);
+      if (ix.text[(uint64_t)ix.sa[m] + d] <= c)
+        a = m + 1;
+      else
+        b = m;
+    }
+    if (a == nlo) break;
+    lo = nlo;
+    hi = a;
+    d++;
+  }
+  out_d = (lo < hi) ? d : 0;
+  out_lo = lo;
+  out_hi = hi;
+}
+
+__global__ __launch_bounds__(256) void seed_kernel(SeedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const uint32_t lcap = (p.max_read_len + 31u) & ~15u;  // >= L + 16, multiple of 16
+  const uint32_t per_wave = lcap * 26;
+  uint8_t* base = smem + (size_t)wave * per_wave;
+  uint8_t* rd = base;                              // lcap
+  uint32_t* a_lo = (uint32_t*)(base + lcap);       // lcap * 4
+  uint32_t* a_hi = a_lo + lcap;                    // lcap * 4
+  uint32_t* s_lo = a_hi + lcap;                    // lcap * 4
+  uint32_t* s_hi = s_lo + lcap;                    // lcap * 4
+  uint16_t* a_end = (uint16_t*)(s_hi + lcap);      // lcap * 2
+  uint16_t* s_pos = a_end + lcap;                  // lcap * 2
+  uint16_t* s_len = s_pos + lcap;                  // lcap * 2
+  uint16_t* s_em = s_len + lcap;                   // lcap * 2
+
+  const int k = (int)p.min_seed_len;
+  unsigned long long c_smems = 0, c_hits = 0;
+  for (;;) {
+    unsigned idx = 0;
+    if (lane == 0) idx = atomicAdd(p.queue, 1u);
+    idx = (unsigned)bcast_first((int)idx);
+    if (idx >= p.reads.n_reads) break;
+    const uint64_t r0 = p.reads.offsets[idx];
+    const int L = (int)(p.reads.offsets[idx + 1] - r0);
+    for (int t = lane; t < (int)lcap; t += 64) rd[t] = (t < L) ? sanitize_base(p.reads.bases[r0 + t]) : (uint8_t)0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+    // matching statistics, one position per lane
+    for (int b0 = 0; b0 < L; b0 += 64) {
+      const int pos = b0 + lane;
+      if (pos < L) {
+        int d = 0;
+        uint32_t lo = 0, hi = 0;
+        if (pos + k <= L) ms_search(p.ix, rd, L, pos, k, d, lo, hi);
+        a_end[pos] = (uint16_t)((d >= k) ? pos + d : 0);
+        a_lo[pos] = lo;
+        a_hi[pos] = hi;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+    // SMEM starts: end[i] > end[i-1]; compacted in start order
+    int n_sm = 0;
+    for (int b0 = 0; b0 < L; b0 += 64) {
+      const int pos = b0 + lane;
+      bool is = false;
+      int e = 0;
+      if (pos < L) {
+        e = a_end[pos];
+        const int prev = pos > 0 ? (int)a_end[pos - 1] : 0;
+        is = e > 0 && e > prev;
+      }
+      const unsigned long long mask = __ballot(is);
+      if (is) {
+        const int at = n_sm + __popcll(mask & ((1ull << lane) - 1ull));
+        s_pos[at] = (uint16_t)pos;
+        s_len[at] = (uint16_t)(e - pos);
+        s_lo[at] = a_lo[pos];
+        s_hi[at] = a_hi[pos];
+      }
+      n_sm += __popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+    // emission order of FMDIndex::all_smems: walk i0; the SMEMs covering i0 come
+    // out by descending start; i0 jumps to the furthest end (or to the next start)
+    {
+      int t = 0, em = 0, i0 = 0;
+      while (t < n_sm) {
+        const int st = s_pos[t];
+        if (st > i0) i0 = st;
+        int u = t;
+        while (u < n_sm && (int)s_pos[u] <= i0) u++;
+        if (lane == 0)
+          for (int v = u - 1; v >= t; v--) s_em[v] = (uint16_t)(em + (u - 1 - v));
+        em += u - t;
+        i0 = (int)s_pos[u - 1] + (int)s_len[u - 1];
+        t = u;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+    // order: length descending, then emission index descending
+    unsigned long long base_out = 0;
+    if (lane == 0 && n_sm > 0) base_out = atomicAdd(p.cursor, (unsigned long long)n_sm);
+    base_out = ((unsigned long long)(unsigned)bcast_first((int)(base_out >> 32)) << 32) |
+               (unsigned)bcast_first((int)(base_out & 0xffffffffu));
+    const bool fits = base_out + (unsigned long long)n_sm <= p.smem_cap;
+    unsigned long long hits = 0;
+    for (int t0 = 0; t0 < n_sm; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < n_sm) {
+        const int len = s_len[t], em = s_em[t];
+        int rank = 0;
+        for (int u = 0; u < n_sm; u++) {
+          const int lu = s_len[u], eu = s_em[u];
+          rank += (lu > len || (lu == len && eu > em)) ? 1 : 0;
+        }
+        if (fits) {
+          Smem s;
+          s.lo = s_lo[t];
+          s.hi = s_hi[t];
+          s.qpos = s_pos[t];
+          s.len = (uint16_t)len;
+          p.smems[base_out + rank] = s;
+        }
+        hits += (unsigned long long)(s_hi[t] - s_lo[t]);
+      }
+    }
+    // wave sum of hits
+    for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
+    if (lane == 0) {
+      if (!fits) atomicExch(p.fault, 1);
+      p.read_smem_off[idx] = base_out;
+      p.read_smem_cnt[idx] = (uint32_t)n_sm;
+      p.read_hits[idx] = hits;
+    }
+    c_smems += (unsigned long long)n_sm;
+    c_hits += hits;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  if (lane == 0 && (c_smems | c_hits)) {
+    atomicAdd(&p.counters[THM_CNT_SMEMS], c_smems);
+    atomicAdd(&p.counters[THM_CNT_HITS], c_hits);
+  }
+}
+
+// Mem list of Index::all_smems for thm_smems_batch: one wave per read
+__global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
+  const int lane = lane_id();
+  const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.n_reads) return;
+  const uint64_t s0 = p.read_smem_off[r];
+  const uint32_t ns = p.read_smem_cnt[r];
+  uint64_t out = p.read_mem_off[r];
+  for (uint32_t s = 0; s < ns; s++) {
+    const Smem sm = p.smems[s0 + s];
+    const uint32_t cnt = sm.hi - sm.lo;
+    for (uint32_t t = lane; t < cnt; t += 64) {
+      thm_mem m;
+      m.ref_idx = p.ix.sa[sm.hi - 1 - t];
+      m.query_idx = sm.qpos;
+      m.len = sm.len;
+      p.mems[out + t] = m;
+    }
+    out += cnt;
+  }
+}
+
+}  // namespace dev
+
+size_t seed_lds_bytes(uint32_t max_read_len) {
+  const uint32_t lcap = (max_read_len + 31u) & ~15u;
+  return 4 * (size_t)lcap * 26;
+}
+
+hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s) {
+  const size_t lds = seed_lds_bytes(p.max_read_len);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)dev::seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(dev::seed_kernel, dim3(n_blocks), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_expand(const ExpandParams& p, hipStream_t s) {
+  const unsigned blocks = (unsigned)((p.n_reads + 3) / 4);
+  if (blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::expand_kernel, dim3(blocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace thm

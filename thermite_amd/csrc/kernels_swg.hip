@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
     for (int t = lane; t < ylen; t += 64) ys[t] = p.yb[y0 + t];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
-    SwgResult r = swg_extend_wave<CPL>(xs, xlen, ys, ylen, bw, xd, trace);
+    SwgResult r = swg_extend_wave<CPL>(xs, 1, xlen, ys, 1, ylen, bw, xd, trace);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     // path from the max cell back to the origin, laid out so that it reads forward
     int nops = swg_traceback_wave<CPL>(trace, r.xend, r.yend, bw, opsb + ops_cap - 1, -1, (int)ops_cap);

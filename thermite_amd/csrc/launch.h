@@ -96,6 +96,7 @@ struct ExtendParams {
   const uint32_t* read_smem_cnt;
   const uint64_t* read_cand_off;  // exclusive prefix sum of read_hits: the read's slice of cands[]
   Cand* cands;
+  uint64_t cand_cap;  // entries in cands[] (order[] holds twice as many u32)
   uint32_t* order;  // [total hits] per-read scratch for the final ordering (indices into the read's slice)
   uint8_t* cand_ops;
   uint64_t cand_ops_cap;

@@ -1,0 +1,336 @@
+// pipeline.hip -- the batched read-level entry points of include/thermite.h:
+//   thm_batch_upload / thm_batch_run / thm_batch_sync / thm_batch_fetch,
+//   thm_align_batch (= the three in sequence) and thm_smems_batch.
+//
+// One batch = count -> scan -> fill on the device:
+//   seed kernel     SMEMs per read (pool + per-read run), hit counts
+//   scan            hit counts -> per-read slice of the candidate array
+//   extend kernel   align_read per read; accepted alignments into the slice,
+//                   op streams into a bump-allocated pool; final order list
+//   scans           alignment counts / op bytes -> output offsets
+//   compact kernel  canonical output (alignments in read order, op streams
+//                   back to back), so the D2H copy is a plain memcpy
+// Pool capacities are heuristics; a kernel that runs out sets a fault bit and
+// thm_batch_sync grows the pools and replays the batch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "aligner_internal.h"
+
+using namespace thm;
+
+namespace {
+
+// bw0(L) of reference src/aligner.rs:130-138; non-decreasing in L
+int band_for_len(const thm_align_opts& o, uint32_t L) {
+  volatile float prod = o.min_aln_score_percent * (float)L;
+  float pv = prod;
+  int pct = (pv != pv) ? 0 : (pv >= 2147483648.0f ? 2147483647 : (pv <= -2147483648.0f ? (-2147483647 - 1) : (int)pv));
+  int ms = std::max(pct, o.min_aln_score);
+  if (ms < 0) return 0;
+  return std::max((int)L - ms, 0);
+}
+
+int blocks_for(const thm_aligner* a, uint64_t n, size_t lds_per_block) {
+  int per_cu = 8;
+  if (lds_per_block > 0) per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds_per_block);
+  if (per_cu < 1) per_cu = 1;
+  return grid_blocks(a, n, 4, per_cu);
+}
+
+int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
+  const uint64_t n = a->n_reads;
+  hipStream_t s = a->stream;
+  HIPCHK(a, a->s_off.ensure((n + 1) * 8));
+  HIPCHK(a, a->s_cnt.ensure((n + 1) * 4));
+  HIPCHK(a, a->s_hits.ensure((n + 1) * 8));
+  HIPCHK(a, a->s_cand_off.ensure((n + 2) * 8));
+  HIPCHK(a, a->scan_tmp.ensure(scan_tmp_entries(n + 1) * 8 + 64));
+  if (a->smem_cap < n * 4 + 4096) a->smem_cap = n * 4 + 4096;
+  HIPCHK(a, a->s_smems.ensure(a->smem_cap * sizeof(Smem)));
+  a->smem_cap = std::max<uint64_t>(a->smem_cap, a->s_smems.cap / sizeof(Smem));
+  int rc = reset_queue(a);
+  if (rc != THM_OK) return rc;
+  HIPCHK(a, hipMemsetAsync(a->d_cursors.p, 0, 64, s));
+  SeedParams sp;
+  sp.ix = a->dix->view;
+  sp.reads.bases = a->r_bases.as<uint8_t>();
+  sp.reads.offsets = a->r_offsets.as<uint64_t>();
+  sp.reads.n_reads = n;
+  sp.min_seed_len = min_seed_len;
+  sp.max_read_len = a->max_read_len;
+  sp.smems = a->s_smems.as<Smem>();
+  sp.smem_cap = a->smem_cap;
+  sp.cursor = a->d_cursors.as<unsigned long long>();
+  sp.read_smem_off = a->s_off.as<uint64_t>();
+  sp.read_smem_cnt = a->s_cnt.as<uint32_t>();
+  sp.read_hits = a->s_hits.as<uint64_t>();
+  sp.counters = a->d_counters.as<unsigned long long>();
+  sp.queue = a->d_queue.as<unsigned int>();
+  sp.fault = a->d_fault.as<int>();
+  HIPCHK(a, launch_seed(sp, blocks_for(a, n, seed_lds_bytes(a->max_read_len)), s));
+  // hit counts -> offsets of each read's slice (also the Mem offsets of thm_smems_batch)
+  HIPCHK(a, launch_exclusive_scan_u64(a->s_hits.as<uint64_t>(), a->s_cand_off.as<uint64_t>(), n,
+                                      a->scan_tmp.as<uint64_t>(), s));
+  return THM_OK;
+}
+
+int enqueue_run(thm_aligner* a) {
+  const uint64_t n = a->n_reads;
+  hipStream_t s = a->stream;
+  const uint32_t bw_max = (uint32_t)band_for_len(a->opts, a->max_read_len);
+  const int cpl = (int)((2 * bw_max + 1 + 63) / 64);
+  if (cpl > 4) return fail(a, THM_ERR_UNSUPPORTED, "band +-%u needs more than 4 cells per lane", bw_max);
+  const size_t lds = extend_lds_bytes(a->max_read_len, bw_max, cpl);
+  if (lds > 64 * 1024)
+    return fail(a, THM_ERR_UNSUPPORTED, "read length %u with band +-%u needs %zu bytes of LDS per workgroup (limit 65536)",
+                a->max_read_len, bw_max, lds);
+  HIPCHK(a, hipEventRecord(a->ev[0], s));
+  int rc = enqueue_seed(a, (uint32_t)a->opts.min_seed_len);
+  if (rc != THM_OK) return rc;
+  HIPCHK(a, hipEventRecord(a->ev[1], s));
+
+  if (a->cand_cap < n * 3 + 1024) a->cand_cap = n * 3 + 1024;
+  if (a->cand_ops_cap < n * 384 + 65536) a->cand_ops_cap = n * 384 + 65536;
+  HIPCHK(a, a->e_cands.ensure(a->cand_cap * sizeof(Cand)));
+  HIPCHK(a, a->e_order.ensure(a->cand_cap * 2 * 4));
+  HIPCHK(a, a->e_ops.ensure(a->cand_ops_cap + 64));
+  HIPCHK(a, a->e_nalns.ensure((n + 1) * 4));
+  HIPCHK(a, a->e_nalns64.ensure((n + 1) * 8));
+  HIPCHK(a, a->e_opbytes.ensure((n + 1) * 8));
+  HIPCHK(a, a->e_aln_off.ensure((n + 2) * 8));
+  HIPCHK(a, a->e_ops_off.ensure((n + 2) * 8));
+  HIPCHK(a, a->o_alns.ensure(a->cand_cap * sizeof(thm_aln)));
+  HIPCHK(a, a->o_ops.ensure(a->cand_ops_cap + 64));
+  HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, 64, s));
+  HIPCHK(a, hipEventRecord(a->ev[2], s));
+
+  ExtendParams ep;
+  ep.ix = a->dix->view;
+  ep.reads.bases = a->r_bases.as<uint8_t>();
+  ep.reads.offsets = a->r_offsets.as<uint64_t>();
+  ep.reads.n_reads = n;
+  ep.opts = a->opts;
+  ep.smems = a->s_smems.as<Smem>();
+  ep.read_smem_off = a->s_off.as<uint64_t>();
+  ep.read_smem_cnt = a->s_cnt.as<uint32_t>();
+  ep.read_cand_off = a->s_cand_off.as<uint64_t>();
+  ep.cands = a->e_cands.as<Cand>();
+  ep.cand_cap = a->cand_cap;
+  ep.order = a->e_order.as<uint32_t>();
+  ep.cand_ops = a->e_ops.as<uint8_t>();
+  ep.cand_ops_cap = a->cand_ops_cap;
+  ep.ops_cursor = a->d_cursors.as<unsigned long long>() + 1;
+  ep.read_n_alns = a->e_nalns.as<uint32_t>();
+  ep.read_op_bytes = a->e_opbytes.as<uint64_t>();
+  ep.counters = a->d_counters.as<unsigned long long>();
+  ep.queue = a->d_queue.as<unsigned int>();
+  ep.fault = a->d_fault.as<int>() + 1;
+  ep.max_read_len = a->max_read_len;
+  ep.max_bw = bw_max;
+  ep.max_cols = a->max_read_len + bw_max + 2;
+  HIPCHK(a, launch_extend(ep, cpl, blocks_for(a, n, lds), s));
+  HIPCHK(a, hipEventRecord(a->ev[3], s));
+
+  HIPCHK(a, launch_widen_u32_to_u64(a->e_nalns.as<uint32_t>(), a->e_nalns64.as<uint64_t>(), n, s));
+  HIPCHK(a, launch_exclusive_scan_u64(a->e_nalns64.as<uint64_t>(), a->e_aln_off.as<uint64_t>(), n,
+                                      a->scan_tmp.as<uint64_t>(), s));
+  HIPCHK(a, launch_exclusive_scan_u64(a->e_opbytes.as<uint64_t>(), a->e_ops_off.as<uint64_t>(), n,
+                                      a->scan_tmp.as<uint64_t>(), s));
+  CompactParams cp;
+  cp.n_reads = n;
+  cp.read_cand_off = a->s_cand_off.as<uint64_t>();
+  cp.cands = a->e_cands.as<Cand>();
+  cp.order = a->e_order.as<uint32_t>();
+  cp.cand_ops = a->e_ops.as<uint8_t>();
+  cp.read_n_alns = a->e_nalns.as<uint32_t>();
+  cp.read_aln_off = a->e_aln_off.as<uint64_t>();
+  cp.read_ops_off = a->e_ops_off.as<uint64_t>();
+  cp.xlen_unused = 0;
+  cp.read_offsets = a->r_offsets.as<uint64_t>();
+  cp.alns = a->o_alns.as<thm_aln>();
+  cp.ops = a->o_ops.as<uint8_t>();
+  HIPCHK(a, launch_compact(cp, s));
+  HIPCHK(a, hipEventRecord(a->ev[4], s));
+  return THM_OK;
+}
+
+// host-visible status words of the last enqueue
+struct RunStatus {
+  int fault_seed = 0, fault_ext = 0;
+  unsigned long long smem_used = 0, ops_used = 0, total_hits = 0;
+};
+int read_status(thm_aligner* a, RunStatus* st) {
+  hipStream_t s = a->stream;
+  int f[2] = {0, 0};
+  unsigned long long cur[2] = {0, 0};
+  HIPCHK(a, hipMemcpyAsync(f, a->d_fault.p, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipMemcpyAsync(cur, a->d_cursors.p, 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipMemcpyAsync(&st->total_hits, a->s_cand_off.as<uint64_t>() + a->n_reads, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipStreamSynchronize(s));
+  st->fault_seed = f[0];
+  st->fault_ext = f[1];
+  st->smem_used = cur[0];
+  st->ops_used = cur[1];
+  return THM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t thm_batch_upload(thm_aligner* a, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads) {
+  if (!a || !offsets || (!bases && n_reads && offsets[n_reads] > 0)) return THM_ERR_INVALID_ARG;
+  HIPCHK(a, hipSetDevice(a->device));
+  a->uploaded = a->ran = a->synced = false;
+  if (n_reads >= 0xFFFFFFF0ull) return fail(a, THM_ERR_UNSUPPORTED, "more than 2^32-16 reads in one batch");
+  uint32_t lmax = 0;
+  for (uint64_t i = 0; i < n_reads; i++) {
+    if (offsets[i + 1] < offsets[i]) return fail(a, THM_ERR_INVALID_ARG, "read offsets are not monotone");
+    uint64_t L = offsets[i + 1] - offsets[i];
+    if (L > 4000) return fail(a, THM_ERR_UNSUPPORTED, "read %llu is %llu bases long (limit 4000)", (unsigned long long)i,
+                              (unsigned long long)L);
+    lmax = std::max<uint32_t>(lmax, (uint32_t)L);
+  }
+  if (offsets[0] != 0) return fail(a, THM_ERR_INVALID_ARG, "offsets[0] must be 0");
+  a->n_reads = n_reads;
+  a->n_bases = offsets[n_reads];
+  a->max_read_len = lmax;
+  HIPCHK(a, a->r_bases.ensure(a->n_bases + 64));
+  HIPCHK(a, a->r_offsets.ensure((n_reads + 1) * 8));
+  if (a->n_bases) HIPCHK(a, hipMemcpyAsync(a->r_bases.p, bases, a->n_bases, hipMemcpyHostToDevice, a->stream));
+  HIPCHK(a, hipMemcpyAsync(a->r_offsets.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, a->stream));
+  HIPCHK(a, hipStreamSynchronize(a->stream));
+  a->uploaded = true;
+  return THM_OK;
+}
+
+int32_t thm_batch_run(thm_aligner* a) {
+  if (!a) return THM_ERR_INVALID_ARG;
+  if (!a->uploaded) return fail(a, THM_ERR_INVALID_ARG, "thm_batch_run before thm_batch_upload");
+  HIPCHK(a, hipSetDevice(a->device));
+  a->ran = false;
+  a->synced = false;
+  int rc = enqueue_run(a);
+  if (rc == THM_OK) a->ran = true;
+  return rc;
+}
+
+int32_t thm_batch_sync(thm_aligner* a) {
+  if (!a) return THM_ERR_INVALID_ARG;
+  if (!a->ran) return fail(a, THM_ERR_INVALID_ARG, "thm_batch_sync before thm_batch_run");
+  if (a->synced) return THM_OK;
+  HIPCHK(a, hipSetDevice(a->device));
+  for (int attempt = 0; attempt < 6; attempt++) {
+    RunStatus st;
+    int rc = read_status(a, &st);
+    if (rc != THM_OK) return rc;
+    if (st.fault_ext & 2) return fail(a, THM_ERR_INTERNAL, "extend kernel reported an internal inconsistency");
+    if (st.fault_ext & 4)
+      return fail(a, THM_ERR_OUT_OF_CONTRACT,
+                  "a read hit a condition that panics in the reference (lift_mem_to_tx / lift_tx_to_gx)");
+    const bool grow = st.fault_seed || (st.fault_ext & 1);
+    if (!grow) {
+      float ms = 0;
+      for (int k = 0; k < 4; k++) {
+        if (hipEventElapsedTime(&ms, a->ev[k], a->ev[k + 1]) == hipSuccess) a->timings[k] = ms;
+      }
+      if (hipEventElapsedTime(&ms, a->ev[0], a->ev[4]) == hipSuccess) a->timings[THM_T_TOTAL] = ms;
+      a->synced = true;
+      return THM_OK;
+    }
+    // grow whatever overflowed and replay (counters of the failed attempt are discarded by the caller's reset)
+    if (st.fault_seed) a->smem_cap = std::max<uint64_t>(a->smem_cap * 2, st.smem_used + 1024);
+    if (st.total_hits > a->cand_cap) a->cand_cap = st.total_hits + st.total_hits / 8 + 1024;
+    if (st.ops_used > a->cand_ops_cap) a->cand_ops_cap = st.ops_used + st.ops_used / 2 + 65536;
+    if (a->cand_cap * sizeof(Cand) > (160ull << 30))
+      return fail(a, THM_ERR_OOM, "batch has %llu seed hits: candidate pool would exceed 160 GiB", st.total_hits);
+    rc = enqueue_run(a);
+    if (rc != THM_OK) return rc;
+  }
+  return fail(a, THM_ERR_INTERNAL, "pools kept overflowing after 6 attempts");
+}
+
+int32_t thm_batch_fetch(thm_aligner* a, thm_batch_view* out) {
+  if (!a || !out) return THM_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  int rc = thm_batch_sync(a);
+  if (rc != THM_OK) return rc;
+  const uint64_t n = a->n_reads;
+  hipStream_t s = a->stream;
+  a->h_off.assign(n + 1, 0);
+  uint64_t n_ops = 0;
+  HIPCHK(a, hipMemcpyAsync(a->h_off.data(), a->e_aln_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipMemcpyAsync(&n_ops, a->e_ops_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipStreamSynchronize(s));
+  const uint64_t n_alns = a->h_off[n];
+  a->h_alns.resize(n_alns);
+  a->h_ops.resize(n_ops);
+  if (n_alns) HIPCHK(a, hipMemcpyAsync(a->h_alns.data(), a->o_alns.p, n_alns * sizeof(thm_aln), hipMemcpyDeviceToHost, s));
+  if (n_ops) HIPCHK(a, hipMemcpyAsync(a->h_ops.data(), a->o_ops.p, n_ops, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipStreamSynchronize(s));
+  out->n_reads = n;
+  out->n_alns = n_alns;
+  out->n_op_bytes = n_ops;
+  out->read_aln_off = a->h_off.data();
+  out->alns = a->h_alns.data();
+  out->ops = a->h_ops.data();
+  return THM_OK;
+}
+
+int32_t thm_align_batch(thm_aligner* a, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
+                        thm_batch_view* out) {
+  int rc = thm_batch_upload(a, bases, offsets, n_reads);
+  if (rc != THM_OK) return rc;
+  rc = thm_batch_run(a);
+  if (rc != THM_OK) return rc;
+  return thm_batch_fetch(a, out);
+}
+
+int32_t thm_smems_batch(thm_aligner* a, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
+                        uint64_t min_seed_len, thm_mems_view* out) {
+  if (!a || !out) return THM_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  if (min_seed_len < 1 || min_seed_len > 65535) return fail(a, THM_ERR_INVALID_ARG, "min_seed_len out of range");
+  int rc = thm_batch_upload(a, bases, offsets, n_reads);
+  if (rc != THM_OK) return rc;
+  const uint64_t n = n_reads;
+  hipStream_t s = a->stream;
+  RunStatus st;
+  for (int attempt = 0;; attempt++) {
+    rc = enqueue_seed(a, (uint32_t)min_seed_len);
+    if (rc != THM_OK) return rc;
+    rc = read_status(a, &st);
+    if (rc != THM_OK) return rc;
+    if (!st.fault_seed) break;
+    if (attempt >= 6) return fail(a, THM_ERR_INTERNAL, "smem pool kept overflowing");
+    a->smem_cap = std::max<uint64_t>(a->smem_cap * 2, st.smem_used + 1024);
+  }
+  a->uploaded = false;  // the seed-only pass leaves no aligned batch behind
+  const uint64_t n_mems = st.total_hits;
+  if (n_mems * sizeof(thm_mem) > (64ull << 30)) return fail(a, THM_ERR_OOM, "%llu seed hits in one batch", st.total_hits);
+  HIPCHK(a, a->o_mems.ensure(n_mems * sizeof(thm_mem) + 64));
+  ExpandParams xp;
+  xp.ix = a->dix->view;
+  xp.n_reads = n;
+  xp.smems = a->s_smems.as<Smem>();
+  xp.read_smem_off = a->s_off.as<uint64_t>();
+  xp.read_smem_cnt = a->s_cnt.as<uint32_t>();
+  xp.read_mem_off = a->s_cand_off.as<uint64_t>();
+  xp.mems = a->o_mems.as<thm_mem>();
+  HIPCHK(a, launch_expand(xp, s));
+  a->h_off.assign(n + 1, 0);
+  a->h_mems.resize(n_mems);
+  HIPCHK(a, hipMemcpyAsync(a->h_off.data(), a->s_cand_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+  if (n_mems) HIPCHK(a, hipMemcpyAsync(a->h_mems.data(), a->o_mems.p, n_mems * sizeof(thm_mem), hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipStreamSynchronize(s));
+  out->n_reads = n;
+  out->n_mems = n_mems;
+  out->read_mem_off = a->h_off.data();
+  out->mems = a->h_mems.data();
+  return THM_OK;
+}
+
+}  // extern "C"

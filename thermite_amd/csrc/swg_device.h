@@ -72,12 +72,14 @@ struct SwgResult {
   unsigned cells, cols;
 };
 
-// One extension.  xs[0..xlen) / ys[0..ylen) are wave-private LDS byte arrays in
-// DP orientation; trace is wave-private LDS with room for (ylen+1)*CPL*2 u64.
-// Every lane returns the same SwgResult.  Contract: 2*bw+1 <= 64*CPL, xd >= bw.
+// One extension.  x[i] = xs[i*dx], y[j] = ys[j*dy] (dx, dy = +1 or -1: a left
+// extension walks the read and the window backwards, reference
+// src/aligner.rs:364-375) are wave-private LDS bytes; trace is wave-private LDS
+// with room for (ylen+1)*CPL*2 u64.  Every lane returns the same SwgResult.
+// Contract: 2*bw+1 <= 64*CPL, xd >= bw.
 template <int CPL>
-__device__ SwgResult swg_extend_wave(const uint8_t* xs, int xlen, const uint8_t* ys, int ylen, int bw, int xd,
-                                     unsigned long long* trace) {
+__device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const uint8_t* ys, int dy, int ylen, int bw,
+                                     int xd, unsigned long long* trace) {
   SwgResult res;
   res.score = 0;
   res.xend = 0;
@@ -109,10 +111,10 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int xlen, const uint8_t*
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
       int b = lane * CPL + c;
-      xc[c] = (b >= 1 && b < rows1) ? (int)xs[b - 1] : 256;
+      xc[c] = (b >= 1 && b < rows1) ? (int)xs[(b - 1) * dx] : 256;
     }
     for (int j = 1; j <= p1_end; j++) {
-      const int yc = (int)ys[j - 1];
+      const int yc = (int)ys[(j - 1) * dy];
       int d[CPL], Cn[CPL], key[CPL];
       const int d_in = wave_shr1(Dv[CPL - 1], MIN_SCORE);  // D[b-1] of the previous column for register 0
       int lane_tot = NEG;
@@ -170,7 +172,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int xlen, const uint8_t*
     res.cols += 1;
     if (top > xlen) break;  // empty row range: band_max = MIN -> X-drop (reference :117-153)
     const int rows_end = min(top + w, xlen + 1);  // exclusive row bound
-    const int yc = (int)ys[j - 1];
+    const int yc = (int)ys[(j - 1) * dy];
     int d[CPL], Cn[CPL], key[CPL], xc[CPL], base[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; c++) base[c] = max(Cv[c] + ge, Dv[c] + ge + go);
@@ -181,7 +183,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int xlen, const uint8_t*
       const int b = lane * CPL + c;
       const int i = top + b;
       const bool valid = (b < w) && (i < rows_end);
-      xc[c] = valid ? (int)xs[i - 1] : 256;
+      xc[c] = valid ? (int)xs[(i - 1) * dx] : 256;
       const int cnext = (c == CPL - 1) ? c_in : base[c + 1];
       Cn[c] = (b >= w - 1) ? MIN_SCORE : cnext;
       d[c] = Dv[c] + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);

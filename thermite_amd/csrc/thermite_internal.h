@@ -44,6 +44,7 @@ struct DeviceIndex {
   const uint32_t* name_rank;  // per ref
   const thm_tx* txs;
   const thm_exon* exons;
+  const uint64_t* exon_txoff;  // per exon: offset of its first base in the transcript
   const uint8_t* tx_seq;
   const TreeNode* exon_tree;
   const TreeNode* gene_tree;
@@ -78,6 +79,7 @@ struct thm_index {
   std::vector<uint32_t> name_rank;  // per ref
   std::vector<thm_tx> txs;
   std::vector<thm_exon> exons;
+  std::vector<uint64_t> exon_txoff;
   std::vector<uint8_t> tx_seq;
   std::vector<thm_span> genes;
   std::vector<thm::TreeNode> exon_tree, gene_tree;

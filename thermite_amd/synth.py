@@ -46,7 +46,9 @@ def simulate_reads(tables, n_reads, read_len=91, sub_rate=0.01, indel_rate=0.001
             r = refs[rng.integers(0, len(refs), len(gi))]
             span = (r["len"].astype(np.int64) - (L + pad)).clip(min=1)
             s = r["start_idx"].astype(np.int64) + (rng.random(len(gi)) * span).astype(np.int64)
-            win[gi] = text[s[:, None] + np.arange(L + pad, dtype=np.int64)[None, :]]
+            g = text[s[:, None] + np.arange(L + pad, dtype=np.int64)[None, :]]
+            clean = ~(g == ord("N")).any(axis=1)  # windows inside N runs would hit every N position: keep the tx read
+            win[gi[clean]] = g[clean]
     # 1-base indels (sparse): handled per affected read
     reads = win[:, :L].copy()
     if indel_rate > 0:
