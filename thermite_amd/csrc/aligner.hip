@@ -139,7 +139,7 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
     return bail(fail(nullptr, THM_ERR_HIP, "hipStreamCreate failed"));
   for (auto& e : a->ev)
     if (hipEventCreate(&e) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipEventCreate failed"));
-  if (a->d_counters.ensure(THM_N_COUNTERS * 8) != hipSuccess || a->d_queue.ensure(64) != hipSuccess ||
+  if (a->d_counters.ensure(THM_N_COUNTERS * 8 * 2) != hipSuccess || a->d_queue.ensure(64) != hipSuccess ||
       a->d_fault.ensure(64) != hipSuccess || a->d_cursors.ensure(64) != hipSuccess)
     return bail(fail(nullptr, THM_ERR_OOM, "scratch allocation failed"));
   (void)hipMemsetAsync(a->d_counters.p, 0, THM_N_COUNTERS * 8, a->stream);

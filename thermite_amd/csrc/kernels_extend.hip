@@ -213,7 +213,8 @@ __device__ unsigned long long emit_ops(Wctx<CPL>& c, const ExtendParams& p, int 
 // in c.ycl), sets gx start/end in concatenated coordinates.
 template <int CPL>
 __device__ int lift_tx_to_gx(Wctx<CPL>& c, const DeviceIndex& ix, const thm_tx& tx, const uint8_t* path, int n,
-                             long long ystart, long long yend, long long& gx_ystart, long long& gx_yend, int& n_y) {
+                             bool trailing_clip, long long ystart, long long yend, long long& gx_ystart,
+                             long long& gx_yend, int& n_y) {
   const thm_exon* ex = ix.exons + tx.exon_begin;
   const uint64_t* toff = ix.exon_txoff + tx.exon_begin;
   const int ne = (int)tx.n_exons;
@@ -261,6 +262,26 @@ __device__ int lift_tx_to_gx(Wctx<CPL>& c, const DeviceIndex& ix, const thm_tx& 
     if (op == OPK_MATCH || op == OPK_SUBST || op == OPK_DEL) i++;
     if (lane == 0) c.lifted[out] = op;
     out++;
+  }
+  // The reference's op list ends with Xclip(L - xend) when the read is clipped on
+  // the right; that op gets its own loop iteration, so an alignment ending exactly
+  // on an exon boundary still receives the intron (and yend moves to the next
+  // exon's start) -- the "extra exon" edge case noted at src/txome.rs:132.
+  if (trailing_clip && e + 1 < ne && exon_sum + (long long)(cur.end - cur.start) <= i) {
+    const thm_exon nxt = ex[e + 1];
+    if (n_y >= MAX_YCLIPS || out >= c.opcap + MAX_YCLIPS) {
+      c.fault |= FAULT_INTERNAL;
+    } else {
+      if (lane == 0) {
+        c.lifted[out] = OPK_YMARK;
+        c.ycl[n_y] = (uint32_t)(nxt.start - cur.end);
+      }
+      out++;
+      n_y++;
+      exon_sum += (long long)(cur.end - cur.start);
+      cur = nxt;
+      e++;
+    }
   }
   if (i != yend) c.fault |= FAULT_CONTRACT;  // assert_eq!(i, tx_aln.yend), :154
   gx_yend = (long long)cur.start + (i - exon_sum);
@@ -504,7 +525,7 @@ __global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
           int sc, xs_, xe_;
           if (have_best && best.score >= gx.score) {
             const thm_tx tx = ix.txs[best_tx];
-            g_n = lift_tx_to_gx(c, ix, tx, best_buf, best.nops, best.ystart, best.yend, cy0, cy1, g_ny);
+            g_n = lift_tx_to_gx(c, ix, tx, best_buf, best.nops, best.xend < L, best.ystart, best.yend, cy0, cy1, g_ny);
             g_path = c.lifted;
             aln_type = THM_ALN_EXONIC;
             type_idx = best_tx;

@@ -87,6 +87,9 @@ int enqueue_run(thm_aligner* a) {
   if (lds > 64 * 1024)
     return fail(a, THM_ERR_UNSUPPORTED, "read length %u with band +-%u needs %zu bytes of LDS per workgroup (limit 65536)",
                 a->max_read_len, bw_max, lds);
+  // counters as they stood before this attempt, so that a replay after a pool overflow does not count twice
+  HIPCHK(a, hipMemcpyAsync(a->d_counters.as<uint8_t>() + THM_N_COUNTERS * 8, a->d_counters.p, THM_N_COUNTERS * 8,
+                           hipMemcpyDeviceToDevice, s));
   HIPCHK(a, hipEventRecord(a->ev[0], s));
   int rc = enqueue_seed(a, (uint32_t)a->opts.min_seed_len);
   if (rc != THM_OK) return rc;
@@ -247,6 +250,8 @@ int32_t thm_batch_sync(thm_aligner* a) {
     if (st.ops_used > a->cand_ops_cap) a->cand_ops_cap = st.ops_used + st.ops_used / 2 + 65536;
     if (a->cand_cap * sizeof(Cand) > (160ull << 30))
       return fail(a, THM_ERR_OOM, "batch has %llu seed hits: candidate pool would exceed 160 GiB", st.total_hits);
+    HIPCHK(a, hipMemcpyAsync(a->d_counters.p, a->d_counters.as<uint8_t>() + THM_N_COUNTERS * 8, THM_N_COUNTERS * 8,
+                             hipMemcpyDeviceToDevice, a->stream));
     rc = enqueue_run(a);
     if (rc != THM_OK) return rc;
   }
@@ -300,6 +305,12 @@ int32_t thm_smems_batch(thm_aligner* a, const uint8_t* bases, const uint64_t* of
   hipStream_t s = a->stream;
   RunStatus st;
   for (int attempt = 0;; attempt++) {
+    if (attempt == 0)
+      HIPCHK(a, hipMemcpyAsync(a->d_counters.as<uint8_t>() + THM_N_COUNTERS * 8, a->d_counters.p, THM_N_COUNTERS * 8,
+                               hipMemcpyDeviceToDevice, s));
+    else
+      HIPCHK(a, hipMemcpyAsync(a->d_counters.p, a->d_counters.as<uint8_t>() + THM_N_COUNTERS * 8, THM_N_COUNTERS * 8,
+                               hipMemcpyDeviceToDevice, s));
     rc = enqueue_seed(a, (uint32_t)min_seed_len);
     if (rc != THM_OK) return rc;
     rc = read_status(a, &st);
