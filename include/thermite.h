@@ -199,6 +199,7 @@ enum {
   THM_CNT_DP_CELLS = 10,
   THM_CNT_DP_COLS = 11,
   THM_CNT_OP_BYTES = 12,
+  THM_CNT_WINDOW_BYTES = 13, /* reference / transcript window bytes staged for extension */
   THM_N_COUNTERS = 16
 };
 

@@ -47,7 +47,7 @@ assert ALN_DT.itemsize == 112 and MEM_DT.itemsize == 16 and SWG_DT.itemsize == 2
 
 N_COUNTERS = 16
 COUNTER_NAMES = ["reads", "aligned", "unmapped", "alns", "exonic", "intronic", "intergenic", "smems", "hits",
-                 "swg_calls", "dp_cells", "dp_cols", "op_bytes"]
+                 "swg_calls", "dp_cells", "dp_cols", "op_bytes", "window_bytes"]
 N_TIMINGS = 8
 TIMING_NAMES = ["seed", "plan", "extend", "compact", "total"]
 

@@ -81,7 +81,7 @@ struct Wctx {
   uint8_t* ser;     // serialised op stream staging
   int* stack;       // interval-tree traversal stack
   int L, opcap, sercap, wcap;
-  unsigned cells, cols, calls;
+  unsigned cells, cols, calls, winbytes;
   int fault;
 };
 
@@ -151,6 +151,7 @@ __device__ void stage_window(Wctx<CPL>& c, const uint8_t* src, long long a, long
     return;
   }
   for (int t = lane_id(); t < n; t += 64) c.win[t] = src[a + t];
+  c.winbytes += (unsigned)n;
   wfence();
 }
 
@@ -322,12 +323,12 @@ __global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
   c.opcap = (int)opcap;
   c.sercap = (int)sercap;
   c.wcap = (int)wcap;
-  c.cells = c.cols = c.calls = 0;
+  c.cells = c.cols = c.calls = c.winbytes = 0;
   c.fault = 0;
 
   const DeviceIndex& ix = p.ix;
   unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_type[3] = {0, 0, 0}, k_reads = 0, k_opb = 0;
-  unsigned long long k_cells = 0, k_cols = 0, k_calls = 0;
+  unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
 
   for (;;) {
     unsigned idx = 0;
@@ -757,7 +758,8 @@ __global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
     k_cells += c.cells;
     k_cols += c.cols;
     k_calls += c.calls;
-    c.cells = c.cols = c.calls = 0;
+    k_win += c.winbytes;
+    c.cells = c.cols = c.calls = c.winbytes = 0;
     wfence();
   }
   for (int t = 0; t < 3; t++)
@@ -776,6 +778,7 @@ __global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
       atomicAdd(&p.counters[THM_CNT_DP_CELLS], k_cells);
       atomicAdd(&p.counters[THM_CNT_DP_COLS], k_cols);
       atomicAdd(&p.counters[THM_CNT_OP_BYTES], k_opb);
+      atomicAdd(&p.counters[THM_CNT_WINDOW_BYTES], k_win);
     }
   }
 }
