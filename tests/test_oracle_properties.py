@@ -1,0 +1,60 @@
+"""Oracle self-consistency (CPU): the literal FMD walk (bio, recalled) against the
+implementation-independent SMEM definition, the phase-1 X-drop claim of SURVEY.md
+Appendix A.5, and sequence-level validity of every alignment it reports."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from thermite_amd import capi, refdata, synth, validate
+
+
+@pytest.fixture(scope="module")
+def chrm(data_dir):
+    t = refdata.load_reference(data_dir + "/GRCh38-2020-A-chrM.fasta", data_dir + "/GRCh38-2020-A-chrM.gtf")
+    return t, orc.Index(t)
+
+
+@pytest.fixture(scope="module")
+def syn():
+    t = synth.synth_reference(length=300000, n_genes=30)
+    return t, orc.Index(t, sa=capi.build_suffix_array(t["text"]))
+
+
+@pytest.mark.parametrize("k", [8, 12, 20])
+def test_fmd_walk_equals_matching_statistics(chrm, syn, k):
+    for t, ix in (chrm, syn):
+        bases, off, _ = synth.simulate_reads(t, 1500, 91, sub_rate=0.02, indel_rate=0.004, intronic_frac=0.3, stream=k)
+        a = ix.all_smems(bases, off, k)
+        b = ix.all_smems(bases, off, k, ms=True)
+        assert np.array_equal(a.offsets, b.offsets)
+        assert np.array_equal(a.mems, b.mems)
+
+
+def test_phase1_xdrop_never_fires_when_xd_ge_bw():
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    swg = orc.Swg(40)
+    for _ in range(4000):
+        x = acgt[rng.integers(0, 4, int(rng.integers(0, 60)))]
+        y = acgt[rng.integers(0, 4, int(rng.integers(0, 90)))]
+        if rng.random() < 0.5 and len(x):
+            y = np.concatenate([x[: int(rng.integers(0, len(x) + 1))], y])
+        bw = int(rng.integers(0, 41))
+        swg.extend(x, y, bw, bw + int(rng.integers(0, 3)))
+    assert swg.phase1_breaks == 0
+
+
+@pytest.mark.parametrize("opts", [capi.DEFAULT_OPTS, capi.CI_OPTS])
+def test_alignments_are_consistent_with_sequences(chrm, syn, opts):
+    for t, ix in (chrm, syn):
+        bases, off, _ = synth.simulate_reads(t, 1500, 91, sub_rate=0.02, indel_rate=0.004, intronic_frac=0.3, stream=2)
+        r = ix.align_batch(bases, off, opts, n_threads=4)
+        assert r.counters[15] == 0
+        n, bad = validate.check_batch(t, bases, off, r)
+        assert n == len(r.alns) and not bad, bad[:5]
+
+
+def test_threshold_math_is_binary32(chrm):
+    """(percent * L as f32) as i32, src/aligner.rs:131: 0.574f32 * 150f32 -> 86."""
+    assert int(np.float32(0.574) * np.float32(150)) == 86
+    assert int(np.float32(0.66) * np.float32(91)) == 60
