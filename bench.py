@@ -176,6 +176,7 @@ def main():
         from oracle import pyoracle as orc
 
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(cores, 16)  # a one-GPU box owns a 16-thread share of the host
         t1 = time.time()
         oix = orc.Index(tables, sa=sa)
         log(rank, "oracle index (BWT/Occ/sampled SA) in %.1fs; timing on %d host threads" % (time.time() - t1, cores))

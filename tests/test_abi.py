@@ -9,7 +9,7 @@ import pytest
 from thermite_amd import capi
 
 
-def test_library_exports_every_declared_symbol():
+def test_library_exports_every_declared_symbol():  # also compiles the C++ mirror header
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "thermite.h")).read()
     declared = set(re.findall(r"\b(thm_[a-z0-9_]+)\s*\(", hdr))
@@ -36,3 +36,11 @@ def test_no_cpu_fallback(data_dir):
     with pytest.raises(capi.ThermiteError) as e:
         capi.Aligner(ix, capi.DEFAULT_OPTS)
     assert e.value.code == capi.ERR_NO_DEVICE
+
+
+def test_cpp_mirror_header_compiles(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "thermite.hpp"\nint main() { thermite::AlignOpts o; return (int)o.min_seed_len - 20; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(root, "include"), "-fsyntax-only", str(src)])
