@@ -20,6 +20,8 @@
 // few scalar stores.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "launch.h"
 #include "swg_device.h"
 
@@ -259,7 +261,7 @@ __device__ int lift_tx_to_gx(Wctx<CPL>& c, const DeviceIndex& ix, const thm_tx& 
       cur = nxt;
       e++;
     }
-    const uint8_t op = path[k];
+    const uint8_t op = (uint8_t)bcast_first((int)path[k]);
     if (op == OPK_MATCH || op == OPK_SUBST || op == OPK_DEL) i++;
     if (lane == 0) c.lifted[out] = op;
     out++;
@@ -294,8 +296,8 @@ struct Accepted {
   int score;
 };
 
-template <int CPL>
-__global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
+template <int CPL, int MINW>
+__global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
         uint32_t my_sa = 0;
         if ((uint32_t)lane < chunk) my_sa = ix.sa[rr - 1 - lane];
         for (uint32_t t = 0; t < chunk; t++) {
-          const long long hr = (long long)(uint32_t)__shfl((int)my_sa, (int)t);
+          const long long hr = (long long)(uint32_t)__builtin_amdgcn_readlane((int)my_sa, bcast_first((int)t));
           // ================= align_seed_hit (src/aligner.rs:198-314) =================
           const int bw = band_width, xd = x_drop;
           const RefInfo ref = idx_to_ref(ix, (uint64_t)hr);
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
             wfence();
             bool stop = false;
             while (sp > 0 && !stop) {
-              const int ni = c.stack[--sp];
+              const int ni = bcast_first(c.stack[--sp]);  // wave-uniform: the node is fetched through the scalar cache
               wfence();
               const TreeNode nd = ix.exon_tree[ni];
               if (qs < nd.max) {
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
               }
               wfence();
               while (sp > 0) {
-                const int ni = c.stack[--sp];
+                const int ni = bcast_first(c.stack[--sp]);
                 wfence();
                 const TreeNode nd = ix.gene_tree[ni];
                 if (qs < nd.max) {
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(256) void extend_kernel(ExtendParams p) {
       int l_score = 0;
       uint64_t l_yend = 0;
       for (uint32_t s = 0; s < m; s++) {
-        const uint32_t ci = lb[s];
+        const uint32_t ci = (uint32_t)bcast_first((int)lb[s]);
         const Cand a = cands[ci];
         if (nres == 0 || a.ystart >= max_end || a.name_rank != l_rank || a.strand != l_strand) {
           max_end = a.yend;
@@ -859,13 +861,25 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
+  // register budget: MINW waves per SIMD (tuning knob THM_EXT_MINW = 2 | 3 | 4)
+  static const int minw = [] {
+    const char* e = getenv("THM_EXT_MINW");
+    const int v = e ? atoi(e) : 2;
+    return (v == 3 || v == 4) ? v : 2;
+  }();
+#define THM_EXT_CASE(C)                                  \
+  case C:                                                \
+    if (minw == 4) return go(dev::extend_kernel<C, 4>);  \
+    if (minw == 3) return go(dev::extend_kernel<C, 3>);  \
+    return go(dev::extend_kernel<C, 2>);
   switch (cpl) {
-    case 1: return go(dev::extend_kernel<1>);
-    case 2: return go(dev::extend_kernel<2>);
-    case 3: return go(dev::extend_kernel<3>);
-    case 4: return go(dev::extend_kernel<4>);
+    THM_EXT_CASE(1)
+    THM_EXT_CASE(2)
+    THM_EXT_CASE(3)
+    THM_EXT_CASE(4)
     default: return hipErrorInvalidValue;
   }
+#undef THM_EXT_CASE
 }
 
 hipError_t launch_compact(const CompactParams& p, hipStream_t s) {

@@ -242,29 +242,73 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
 // Reference trace(), src/swg.rs:170-207, without the leading Xclip.  Walks from
 // (i, j) back to the origin; op k of the walk (k = 0 is the cell at the max) is
 // written to ops[k * stride] with stride = +1 or -1 (so a caller can lay the
-// path out in either direction).  Uniform across the wave; lane 0 stores.
-// Returns the number of ops, or -1 on an inconsistent trace.
+// path out in either direction).  Returns the number of ops, or -1 on an
+// inconsistent trace.
+//
+// The walk is a serial dependency chain, so it is kept off the memory pipes:
+// the ballot words of 64 consecutive columns are loaded into registers at once
+// (lane t holds column jhi - t), each step picks its word with v_readlane and
+// does the bit test on the scalar unit, and the ops are collected with
+// v_writelane and flushed to LDS 64 at a time.
 template <int CPL>
 __device__ int swg_traceback_wave(const unsigned long long* trace, int i, int j, int bw, uint8_t* ops, int stride,
                                   int max_ops) {
   const int lane = lane_id();
+  i = bcast_first(i);
+  j = bcast_first(j);
+  bw = bcast_first(bw);
   int n = 0;
+  int jhi = -1;
+  int w_ll[CPL], w_lh[CPL], w_hl[CPL], w_hh[CPL];  // lo/hi ballot words split in 32-bit halves
+#pragma unroll
+  for (int c = 0; c < CPL; c++) w_ll[c] = w_lh[c] = w_hl[c] = w_hh[c] = 0;
+  int acc = 0;  // lane (n & 63) holds op n of the current group of 64
   while (i > 0 || j > 0) {
     int op;
     if (j == 0) {
       op = OPK_INS;  // column 0 is all Ins (reference :65,:70)
     } else {
+      if (jhi < 0 || j < jhi - 63) {
+        jhi = j;
+        const int col = j - lane;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+          unsigned long long lo = 0, hi = 0;
+          if (col >= 1) {
+            lo = trace[((size_t)col * CPL + c) * 2 + 0];
+            hi = trace[((size_t)col * CPL + c) * 2 + 1];
+          }
+          w_ll[c] = (int)(unsigned)lo;
+          w_lh[c] = (int)(unsigned)(lo >> 32);
+          w_hl[c] = (int)(unsigned)hi;
+          w_hh[c] = (int)(unsigned)(hi >> 32);
+        }
+      }
+      const int t = jhi - j;
       const int top = max(j - bw, 0);
       const int b = i - top;
       if (b < 0 || b >= 64 * CPL) return -1;
       const int l = b / CPL, c = b % CPL;
-      const unsigned long long lo = trace[((size_t)j * CPL + c) * 2 + 0];
-      const unsigned long long hi = trace[((size_t)j * CPL + c) * 2 + 1];
-      op = (int)((lo >> l) & 1ull) | ((int)((hi >> l) & 1ull) << 1);
+      unsigned wl = 0, wh = 0;
+#pragma unroll
+      for (int cc = 0; cc < CPL; cc++) {
+        if (c == cc) {
+          if (l < 32) {
+            wl = (unsigned)__builtin_amdgcn_readlane(w_ll[cc], t);
+            wh = (unsigned)__builtin_amdgcn_readlane(w_hl[cc], t);
+          } else {
+            wl = (unsigned)__builtin_amdgcn_readlane(w_lh[cc], t);
+            wh = (unsigned)__builtin_amdgcn_readlane(w_hh[cc], t);
+          }
+        }
+      }
+      const int lb = l & 31;
+      op = (int)((wl >> lb) & 1u) | ((int)((wh >> lb) & 1u) << 1);
     }
     if (n >= max_ops) return -1;
-    if (lane == 0) ops[n * stride] = (uint8_t)op;
+    acc = (lane == (n & 63)) ? op : acc;
     n++;
+    if ((n & 63) == 0) ops[(n - 64 + lane) * stride] = (uint8_t)acc;
     if (op == OPK_MATCH || op == OPK_SUBST) {
       i--;
       j--;
@@ -275,6 +319,7 @@ __device__ int swg_traceback_wave(const unsigned long long* trace, int i, int j,
     }
     if (i < 0 || j < 0) return -1;
   }
+  if ((n & 63) != 0 && lane < (n & 63)) ops[((n & ~63) + lane) * stride] = (uint8_t)acc;
   return n;
 }
 

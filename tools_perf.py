@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Quick stage timing on the GPU box (tuning aid, not the benchmark):
+python tools_perf.py [ref_len] [n_reads] [opts]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from thermite_amd import capi, synth
+
+ref_len = int(sys.argv[1]) if len(sys.argv) > 1 else 4000000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 500000
+which = sys.argv[3] if len(sys.argv) > 3 else "both"
+t = synth.synth_reference(length=ref_len)
+ix = capi.Index(t)
+bases, off, _ = synth.simulate_reads(t, n, 91, sub_rate=0.01, indel_rate=0.001, stream=100)
+for name, opts in (("ci", capi.CI_OPTS), ("default", capi.DEFAULT_OPTS)):
+    if which not in ("both", name):
+        continue
+    a = capi.Aligner(ix, opts)
+    a.upload(bases, off)
+    for _ in range(2):
+        a.run(); a.sync()
+    acc = {}
+    K = 5
+    t0 = time.perf_counter()
+    for _ in range(K):
+        a.run(); a.sync()
+        for k, v in a.timings().items():
+            acc[k] = acc.get(k, 0.0) + v / K
+    dt = (time.perf_counter() - t0) / K
+    print("%-8s ref=%d n=%d  %.2f Mreads/s  wall %.2f ms  " % (name, ref_len, n, n / dt / 1e6, dt * 1e3) +
+          " ".join("%s=%.2f" % kv for kv in acc.items()), flush=True)
+    a.close()
