@@ -58,7 +58,8 @@ def check_align(w, bases, off, opts, n_threads=8):
     assert r.counters[15] == 0, "oracle saw reads where the reference would panic"
     assert_batch_equal(g, r)
     c = a.counters()
-    assert np.array_equal(c[:13], r.counters[:13]), (c[:13], r.counters[:13])
+    assert np.array_equal(c[:10], r.counters[:10]) and c[12] == r.counters[12], (c[:13], r.counters[:13])
+    assert c[10] <= r.counters[10] and c[11] <= r.counters[11]  # DP work: exact early exit computes fewer cells
     a.close()
     return g
 

@@ -74,7 +74,8 @@ def test_fuzz_vs_oracle(aligner, bw_lo, bw_hi, max_len, n):
     ref = orc.swg_extend_batch(xb, xo, yb, yo, bw, xd, bw_hi)
     assert_swg_equal(alns, ops, ref)
     c = aligner.counters()
-    assert c[9] == ref.counters[9] and c[10] == ref.counters[10] and c[11] == ref.counters[11]
+    # calls match; cells/columns are <= the reference's because of the exact early exit (swg_device.h)
+    assert c[9] == ref.counters[9] and c[10] <= ref.counters[10] and c[11] <= ref.counters[11]
 
 
 def test_empty_inputs(aligner):

@@ -69,14 +69,48 @@ __device__ __forceinline__ int bcast_first(int v) { return __builtin_amdgcn_read
 
 struct SwgResult {
   int score, xend, yend;
-  unsigned cells, cols;
+  unsigned cells, cols;  // cells / columns actually computed (the early exit below makes this <= the reference's count)
 };
+
+// ---- fused DPP steps for the per-column scan (the hot loop) ----
+// `v_max_i32_dpp v, v, v <ctrl>`: lanes whose DPP source is out of range (or masked
+// out) are simply not written, so they keep their own v -- exactly max(v, identity).
+// One instruction per step instead of mov-identity + mov_dpp + max.  The two wait
+// states a DPP read needs after a VALU write are in the asm (hipcc pads nothing
+// inside an asm statement).
+#define THM_DPP_MAX_STEP(v, ctrl) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl : "+v"(v))
+__device__ __forceinline__ int wave_excl_max_scan_fast(int v) {
+  int r = NEG;
+  asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+  THM_DPP_MAX_STEP(r, "row_shr:1 row_mask:0xf bank_mask:0xf");
+  THM_DPP_MAX_STEP(r, "row_shr:2 row_mask:0xf bank_mask:0xf");
+  THM_DPP_MAX_STEP(r, "row_shr:4 row_mask:0xf bank_mask:0xf");
+  THM_DPP_MAX_STEP(r, "row_shr:8 row_mask:0xf bank_mask:0xf");
+  THM_DPP_MAX_STEP(r, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  THM_DPP_MAX_STEP(r, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  return r;
+}
+
+static_assert(MATCH_SCORE == 1 && MISMATCH_SCORE <= 0 && GAP_OPEN <= 0 && GAP_EXTEND <= 0,
+              "the running-max and early-exit logic below relies on +1 per column at most");
 
 // One extension.  x[i] = xs[i*dx], y[j] = ys[j*dy] (dx, dy = +1 or -1: a left
 // extension walks the read and the window backwards, reference
 // src/aligner.rs:364-375) are wave-private LDS bytes; trace is wave-private LDS
 // with room for (ylen+1)*CPL*2 u64.  Every lane returns the same SwgResult.
 // Contract: 2*bw+1 <= 64*CPL, xd >= bw.
+//
+// Per column there is no wave reduction besides the scan for R:
+//   * every cell of column j derives from column j-1 by moves worth at most +1,
+//     so the running maximum rises by exactly 1 iff some lane beats it (a ballot);
+//   * X-drop (reference :151: band_max < max_score - x_drop) is "no lane has
+//     D >= max_score - x_drop" (a ballot);
+//   * early exit: if no cell of this column can still exceed max_score even by
+//     matching all of its remaining x (D + (|x| - i) <= max_score for every band
+//     cell), no later cell can, because every path to a later column crosses this
+//     one.  The reference would keep computing until its X-drop fires, but its
+//     result (strict `>` on max_score) cannot change any more.  Same score, same
+//     end cell, same trace cells on the path.
 template <int CPL>
 __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const uint8_t* ys, int dy, int ylen, int bw,
                                      int xd, unsigned long long* trace) {
@@ -102,6 +136,8 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
   }
   int best = 0, best_i = 0, best_j = 0;  // per lane; reference max_score starts at 0
   int run_max = 0;
+  bool finished = false;
+  unsigned long long* tr = trace + (size_t)CPL * 2;  // column 1
 
   // ---------------- phase 1: band rows 0..w-1 (reference :75-113) ----------------
   const int p1_end = min(bw, ylen);
@@ -110,8 +146,9 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
     int xc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
-      int b = lane * CPL + c;
-      xc[c] = (b >= 1 && b < rows1) ? (int)xs[(b - 1) * dx] : 256;
+      const int b = lane * CPL + c;
+      const int xv = (int)xs[min(max(b - 1, 0), xlen - 1) * dx];
+      xc[c] = (b >= 1 && b < rows1) ? xv : 256;
     }
     for (int j = 1; j <= p1_end; j++) {
       const int yc = (int)ys[(j - 1) * dy];
@@ -129,8 +166,8 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         key[c] = valid ? dp - b * ge : NEG;
         lane_tot = max(lane_tot, key[c]);
       }
-      int run = wave_excl_max_scan(lane_tot);
-      int lmax = NEG;
+      int run = wave_excl_max_scan_fast(lane_tot);
+      bool improve = false, alive = false;
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
@@ -139,91 +176,102 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         run = max(run, key[c]);
         const int dp = max(d[c], Cn[c]);
         const int Dn = max(dp, R);
-        int dir = (Dn == d[c]) ? ((xc[c] == yc && b > 0) ? OPK_MATCH : OPK_SUBST) : ((Dn == Cn[c]) ? OPK_DEL : OPK_INS);
+        const int dir = (Dn == d[c]) ? ((xc[c] == yc) ? OPK_MATCH : OPK_SUBST) : ((Dn == Cn[c]) ? OPK_DEL : OPK_INS);
         const unsigned long long lo = __ballot((dir & 1) != 0);
         const unsigned long long hi = __ballot((dir & 2) != 0);
         if (lane == 0) {
-          trace[((size_t)j * CPL + c) * 2 + 0] = lo;
-          trace[((size_t)j * CPL + c) * 2 + 1] = hi;
+          tr[c * 2 + 0] = lo;
+          tr[c * 2 + 1] = hi;
         }
-        if (valid) {
-          if (Dn > best) {
-            best = Dn;
-            best_i = b;
-            best_j = j;
-          }
-          lmax = max(lmax, Dn);
-          Dv[c] = Dn;
-          Cv[c] = Cn[c];
-        }
+        const bool better = valid && (Dn > best);
+        best = better ? Dn : best;
+        best_i = better ? b : best_i;
+        best_j = better ? j : best_j;
+        improve = improve || (valid && Dn > run_max);
+        alive = alive || (valid && (Dn + (xlen - b) > run_max));
+        Dv[c] = valid ? Dn : Dv[c];
+        Cv[c] = valid ? Cn[c] : Cv[c];
       }
-      const int band_max = wave_max(lmax);
-      run_max = max(run_max, band_max);
+      tr += CPL * 2;
       res.cells += (unsigned)rows1;
       res.cols += 1;
-      // reference :110: with x_drop >= band_width this test can never fire
-      // (SURVEY.md Appendix A.5), so phase 1 always runs to p1_end.
+      if (__ballot(improve)) run_max += MATCH_SCORE;
+      // reference :110: with x_drop >= band_width the X-drop test cannot fire in
+      // phase 1; the early exit is ours (see above)
+      if (!__ballot(alive)) {  // (an improving lane is alive by construction)
+        finished = true;
+        break;
+      }
     }
   }
 
   // ---------------- phase 2: band slides down (reference :116-154) ----------------
-  for (int j = bw + 1; j <= ylen; j++) {
-    const int top = j - bw;
-    res.cols += 1;
-    if (top > xlen) break;  // empty row range: band_max = MIN -> X-drop (reference :117-153)
-    const int rows_end = min(top + w, xlen + 1);  // exclusive row bound
-    const int yc = (int)ys[(j - 1) * dy];
-    int d[CPL], Cn[CPL], key[CPL], xc[CPL], base[CPL];
+  if (!finished) {
+    for (int j = bw + 1; j <= ylen; j++) {
+      const int top = j - bw;
+      res.cols += 1;
+      if (top > xlen) break;  // empty row range: band_max = MIN -> X-drop (reference :117-153)
+      const int rows_end = min(top + w, xlen + 1);  // exclusive row bound
+      const int yc = (int)ys[(j - 1) * dy];
+      int d[CPL], Cn[CPL], key[CPL], xc[CPL], base[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; c++) base[c] = max(Cv[c] + ge, Dv[c] + ge + go);
-    const int c_in = wave_shl1(base[0], MIN_SCORE);  // slot b+1 of the previous column for the last register
-    int lane_tot = NEG;
+      for (int c = 0; c < CPL; c++) base[c] = max(Cv[c] + ge, Dv[c] + ge + go);
+      const int c_in = wave_shl1(base[0], MIN_SCORE);  // slot b+1 of the previous column for the last register
+      int lane_tot = NEG;
 #pragma unroll
-    for (int c = 0; c < CPL; c++) {
-      const int b = lane * CPL + c;
-      const int i = top + b;
-      const bool valid = (b < w) && (i < rows_end);
-      xc[c] = valid ? (int)xs[(i - 1) * dx] : 256;
-      const int cnext = (c == CPL - 1) ? c_in : base[c + 1];
-      Cn[c] = (b >= w - 1) ? MIN_SCORE : cnext;
-      d[c] = Dv[c] + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);
-      const int dp = max(d[c], Cn[c]);
-      key[c] = valid ? dp - b * ge : NEG;
-      lane_tot = max(lane_tot, key[c]);
-    }
-    int run = wave_excl_max_scan(lane_tot);
-    int lmax = NEG;
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-      const int b = lane * CPL + c;
-      const int i = top + b;
-      const bool valid = (b < w) && (i < rows_end);
-      const int R = run + go + b * ge;
-      run = max(run, key[c]);
-      const int dp = max(d[c], Cn[c]);
-      const int Dn = max(dp, R);
-      int dir = (Dn == d[c]) ? ((xc[c] == yc) ? OPK_MATCH : OPK_SUBST) : ((Dn == Cn[c]) ? OPK_DEL : OPK_INS);
-      const unsigned long long lo = __ballot((dir & 1) != 0);
-      const unsigned long long hi = __ballot((dir & 2) != 0);
-      if (lane == 0) {
-        trace[((size_t)j * CPL + c) * 2 + 0] = lo;
-        trace[((size_t)j * CPL + c) * 2 + 1] = hi;
+      for (int c = 0; c < CPL; c++) {
+        const int b = lane * CPL + c;
+        const int i = top + b;
+        const bool valid = (b < w) && (i < rows_end);
+        const int xv = (int)xs[(min(i, xlen) - 1) * dx];
+        xc[c] = valid ? xv : 256;
+        const int cnext = (c == CPL - 1) ? c_in : base[c + 1];
+        Cn[c] = (b >= w - 1) ? MIN_SCORE : cnext;
+        d[c] = Dv[c] + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);
+        const int dp = max(d[c], Cn[c]);
+        key[c] = valid ? dp - b * ge : NEG;
+        lane_tot = max(lane_tot, key[c]);
       }
-      if (valid) {
-        if (Dn > best) {
-          best = Dn;
-          best_i = i;
-          best_j = j;
+      int run = wave_excl_max_scan_fast(lane_tot);
+      bool improve = false, alive = false, xalive = false;
+      const int xfloor = run_max - xd;  // tested against the updated run_max below
+#pragma unroll
+      for (int c = 0; c < CPL; c++) {
+        const int b = lane * CPL + c;
+        const int i = top + b;
+        const bool valid = (b < w) && (i < rows_end);
+        const int R = run + go + b * ge;
+        run = max(run, key[c]);
+        const int dp = max(d[c], Cn[c]);
+        const int Dn = max(dp, R);
+        const int dir = (Dn == d[c]) ? ((xc[c] == yc) ? OPK_MATCH : OPK_SUBST) : ((Dn == Cn[c]) ? OPK_DEL : OPK_INS);
+        const unsigned long long lo = __ballot((dir & 1) != 0);
+        const unsigned long long hi = __ballot((dir & 2) != 0);
+        if (lane == 0) {
+          tr[c * 2 + 0] = lo;
+          tr[c * 2 + 1] = hi;
         }
-        lmax = max(lmax, Dn);
-        Dv[c] = Dn;
+        const bool better = valid && (Dn > best);
+        best = better ? Dn : best;
+        best_i = better ? i : best_i;
+        best_j = better ? j : best_j;
+        improve = improve || (valid && Dn > run_max);
+        // X-drop survivor w.r.t. the updated maximum: if some lane improves, that lane itself survives
+        xalive = xalive || (valid && Dn >= xfloor);
+        alive = alive || (valid && (Dn + (xlen - i) > run_max));
+        Dv[c] = valid ? Dn : Dv[c];
+        Cv[c] = Cn[c];
       }
-      Cv[c] = Cn[c];
+      tr += CPL * 2;
+      res.cells += (unsigned)(rows_end - top);
+      const bool any_improve = __ballot(improve) != 0;
+      if (any_improve) {
+        run_max += MATCH_SCORE;
+        continue;  // the improving cell equals the new maximum: neither X-drop nor the early exit can apply
+      }
+      if (!__ballot(xalive)) break;  // reference :151  band_max < max_score - x_drop
+      if (!__ballot(alive)) break;   // early exit: the result can no longer change
     }
-    const int band_max = wave_max(lmax);
-    run_max = max(run_max, band_max);
-    res.cells += (unsigned)(rows_end - top);
-    if (band_max < run_max - xd) break;  // reference :151
   }
 
   // ---------------- argmax across lanes: first (j, i) attaining the maximum ----------------
