@@ -12,7 +12,7 @@ import numpy as np
 from .refdata import EXON_DT, REF_DT, SPAN_DT, TX_DT  # noqa: F401  (re-exported)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "_build", "libthermite_amd.so")
+SO_PATH = os.environ.get("THM_LIB") or os.path.join(_HERE, "_build", "libthermite_amd.so")
 
 MEM_DT = np.dtype([("ref_idx", "<u8"), ("query_idx", "<u4"), ("len", "<u4")])
 ALN_DT = np.dtype(
@@ -156,6 +156,9 @@ def lib():
     L.thm_timings_get.argtypes = [vp, vp]
     L.thm_version.restype = C.c_char_p
     L.thm_device_count.restype = i32
+    if hasattr(L, "thm_debug_prof_get"):
+        L.thm_debug_prof_get.restype = i32
+        L.thm_debug_prof_get.argtypes = [vp, vp, i32]
     if hasattr(L, "thm_debug_wave_prims"):
         L.thm_debug_wave_prims.restype = i32
         L.thm_debug_wave_prims.argtypes = [vp, vp, vp]
@@ -322,6 +325,11 @@ class Aligner:
         out = np.zeros(N_TIMINGS, "<f4")
         self._chk(lib().thm_timings_get(self.h, _ptr(out)))
         return dict(zip(TIMING_NAMES, out.tolist()))
+
+    def debug_prof(self, reset=True):
+        out = np.zeros(16, "<u8")
+        self._chk(lib().thm_debug_prof_get(self.h, _ptr(out), int(reset)))
+        return out
 
     def debug_wave_prims(self, v):
         v = np.ascontiguousarray(v, "<i4")

@@ -139,10 +139,10 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
     return bail(fail(nullptr, THM_ERR_HIP, "hipStreamCreate failed"));
   for (auto& e : a->ev)
     if (hipEventCreate(&e) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipEventCreate failed"));
-  if (a->d_counters.ensure(THM_N_COUNTERS * 8 * 2) != hipSuccess || a->d_queue.ensure(64) != hipSuccess ||
+  if (a->d_counters.ensure(THM_N_COUNTERS * 8 * 3) != hipSuccess || a->d_queue.ensure(64) != hipSuccess ||
       a->d_fault.ensure(64) != hipSuccess || a->d_cursors.ensure(64) != hipSuccess)
     return bail(fail(nullptr, THM_ERR_OOM, "scratch allocation failed"));
-  (void)hipMemsetAsync(a->d_counters.p, 0, THM_N_COUNTERS * 8, a->stream);
+  (void)hipMemsetAsync(a->d_counters.p, 0, THM_N_COUNTERS * 8 * 3, a->stream);
   int rc = get_dev_copy(a);
   if (rc != THM_OK) return bail(rc);
   rc = thm_aligner_set_opts(a, opts);
@@ -293,7 +293,18 @@ int32_t thm_swg_extend_batch(thm_aligner* a, const uint8_t* x_bases, const uint6
   return THM_OK;
 }
 
-// debug hook used by tests/test_gpu_primitives.py: wave scan / shift primitives
+// tuning hook: per-section shader clocks of the extend kernel (all zero unless built with -DTHM_PROF)
+int32_t thm_debug_prof_get(thm_aligner* a, uint64_t out[16], int32_t reset) {
+  if (!a || !out) return THM_ERR_INVALID_ARG;
+  HIPCHK(a, hipSetDevice(a->device));
+  uint8_t* p = a->d_counters.as<uint8_t>() + 2 * THM_N_COUNTERS * 8;
+  HIPCHK(a, hipMemcpyAsync(out, p, 16 * 8, hipMemcpyDeviceToHost, a->stream));
+  if (reset) HIPCHK(a, hipMemsetAsync(p, 0, 16 * 8, a->stream));
+  HIPCHK(a, hipStreamSynchronize(a->stream));
+  return THM_OK;
+}
+
+// debug hook used by tests/test_gpu_swg.py: wave scan / shift primitives
 int32_t thm_debug_wave_prims(thm_aligner* a, const int32_t in[64], int32_t out[384]) {
   if (!a || !in || !out) return THM_ERR_INVALID_ARG;
   HIPCHK(a, hipSetDevice(a->device));

@@ -85,7 +85,28 @@ struct Wctx {
   int L, opcap, sercap, wcap;
   unsigned cells, cols, calls, winbytes;
   int fault;
+#ifdef THM_PROF
+  unsigned long long prof_last;
+  unsigned long long prof_acc[10];
+#endif
 };
+
+// Section timing for tuning builds (-DTHM_PROF, libthermite_amd_prof.so): every
+// mark charges the shader clocks since the previous mark to one slot.
+enum { PS_SETUP = 0, PS_STAGE = 1, PS_DP = 2, PS_TRACEBACK = 3, PS_TREE = 4, PS_TXPREP = 5, PS_LIFT = 6, PS_EMIT = 7,
+       PS_FINAL = 8, PS_OTHER = 9 };
+#ifdef THM_PROF
+#define PROF_MARK(c, slot)                                       \
+  do {                                                           \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    (c).prof_acc[slot] += t_ - (c).prof_last;                    \
+    (c).prof_last = t_;                                          \
+  } while (0)
+#else
+#define PROF_MARK(c, slot) \
+  do {                     \
+  } while (0)
+#endif
 
 struct Path {
   int score, xstart, xend, nops;
@@ -103,10 +124,13 @@ __device__ Path extend_lr(Wctx<CPL>& c, long long win0, long long lo_abs, long l
   const int xr = L - (q + len);
   const long long yr_avail = hi_abs - (r + len);
   const int yr = (int)min(yr_avail, (long long)(xr + bw + 1));
+  PROF_MARK(c, PS_OTHER);
   const SwgResult R = swg_extend_wave<CPL>(c.rd + q + len, 1, xr, c.win + (r + len - win0), 1, yr, bw, xd, c.trace);
   wfence();
+  PROF_MARK(c, PS_DP);
   int nr = swg_traceback_wave<CPL>(c.trace, R.xend, R.yend, bw, buf + c.opcap - 1, -1, c.opcap);
   wfence();
+  PROF_MARK(c, PS_TRACEBACK);
   // left: both reversed, y = ref_seq[r.saturating_sub(L+bw)..r]   (:364-375)
   const int xl = q;
   const long long rel = r - lo_abs;
@@ -114,6 +138,7 @@ __device__ Path extend_lr(Wctx<CPL>& c, long long win0, long long lo_abs, long l
   const int yl = (int)min(r - y0, (long long)(xl + bw + 1));
   const SwgResult Lt = swg_extend_wave<CPL>(c.rd + q - 1, -1, xl, c.win + (r - 1 - win0), -1, yl, bw, xd, c.trace);
   wfence();
+  PROF_MARK(c, PS_DP);
   int nl = (nr >= 0) ? swg_traceback_wave<CPL>(c.trace, Lt.xend, Lt.yend, bw, buf, 1, c.opcap - nr) : -1;
   wfence();
   c.cells += R.cells + Lt.cells;
@@ -135,6 +160,7 @@ __device__ Path extend_lr(Wctx<CPL>& c, long long win0, long long lo_abs, long l
     if (t < nr) buf[nl + len + t] = v;
     wfence();
   }
+  PROF_MARK(c, PS_TRACEBACK);
   p.nops = nl + len + nr;
   p.score = Lt.score + len * MATCH_SCORE + R.score;
   p.ystart = r - Lt.yend;
@@ -155,6 +181,7 @@ __device__ void stage_window(Wctx<CPL>& c, const uint8_t* src, long long a, long
   for (int t = lane_id(); t < n; t += 64) c.win[t] = src[a + t];
   c.winbytes += (unsigned)n;
   wfence();
+  PROF_MARK(c, PS_STAGE);
 }
 
 // serialise a path (kinds 0..3, 5 = intron marker) into c.ser; lane 0 writes.
@@ -289,6 +316,7 @@ __device__ int lift_tx_to_gx(Wctx<CPL>& c, const DeviceIndex& ix, const thm_tx& 
   if (i != yend) c.fault |= FAULT_CONTRACT;  // assert_eq!(i, tx_aln.yend), :154
   gx_yend = (long long)cur.start + (i - exon_sum);
   wfence();
+  PROF_MARK(c, PS_LIFT);
   return out;
 }
 
@@ -327,6 +355,10 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   c.wcap = (int)wcap;
   c.cells = c.cols = c.calls = c.winbytes = 0;
   c.fault = 0;
+#ifdef THM_PROF
+  for (int t = 0; t < 10; t++) c.prof_acc[t] = 0;
+  c.prof_last = __builtin_amdgcn_s_memtime();
+#endif
 
   const DeviceIndex& ix = p.ix;
   unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_type[3] = {0, 0, 0}, k_reads = 0, k_opb = 0;
@@ -363,6 +395,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
     const uint64_t n_hits_cap = p.read_cand_off[idx + 1] - cand0;
     uint32_t n_acc = 0;
 
+    PROF_MARK(c, PS_SETUP);
     const uint64_t s0 = p.read_smem_off[idx];
     uint32_t n_sm = p.read_smem_cnt[idx];
     if (p.read_cand_off[idx + 1] > p.cand_cap) {  // candidate pool too small: the host grows it and reruns
@@ -390,6 +423,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           Path gx = extend_lr(c, seq_start, seq_start, seq_end, hr, q, len, bw, xd, c.pa);
           uint8_t* gx_path = c.pa;
 
+          PROF_MARK(c, PS_OTHER);
           // transcripts whose exons overlap the seed (:231-258), IntervalTree::find order
           bool have_best = false;
           uint32_t best_tx = 0;
@@ -433,6 +467,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
                   }
                   wfence();
                   if (qs < nd.end && nd.start < qe) {
+                    PROF_MARK(c, PS_TREE);
                     // ---- one transcript ----
                     const uint32_t tx_idx = nd.value;
                     const thm_tx tx = ix.txs[tx_idx];
@@ -502,6 +537,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
                         t_q -= ext;
                         t_len += ext;
                       }
+                      PROF_MARK(c, PS_TXPREP);
                       Path ta = extend_lr(c, ws, 0, tlen, t_r, t_q, t_len, bw, xd, cur_buf);
                       if (!have_best || ta.score > best.score) {  // strictly better (:249)
                         have_best = true;
@@ -519,6 +555,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
             }
           }
 
+          PROF_MARK(c, PS_TREE);
           // ---- exonic vs unspliced (:263-313) ----
           int aln_type;
           uint32_t type_idx = THM_NO_IDX;
@@ -579,6 +616,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               }
             }
           }
+          PROF_MARK(c, PS_TREE);
           // ================= back in align_read's loop (:146-174) =================
           bool accept = intron_mode || aln_type == THM_ALN_EXONIC;
           if (sc < p.opts.min_aln_score || sc < min_aln_score || sc < max_aln_score - range) accept = false;
@@ -641,6 +679,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               cands[n_acc] = cd;
             }
             n_acc++;
+            PROF_MARK(c, PS_EMIT);
             // narrow the band (:162-172)
             const int lim = max(L + range - sc, 0);
             band_width = min(band_width, lim);
@@ -652,6 +691,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
       }
     }
     __threadfence_block();
+    PROF_MARK(c, PS_OTHER);
 
     // ============ retain / filter_overlapping / sort / primary (:177-187) ============
     uint32_t* la = order;               // list A
@@ -750,6 +790,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
       p.read_n_alns[idx] = nres;
       p.read_op_bytes[idx] = opb;
     }
+    PROF_MARK(c, PS_FINAL);
     k_reads++;
     if (nres)
       k_aligned++;
@@ -766,6 +807,10 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   }
   for (int t = 0; t < 3; t++)
     for (int o = 32; o > 0; o >>= 1) k_type[t] += __shfl_xor(k_type[t], o);
+#ifdef THM_PROF
+  if (lane == 0 && p.prof)
+    for (int t = 0; t < 10; t++) atomicAdd(&p.prof[t], c.prof_acc[t]);
+#endif
   if (lane == 0) {
     if (c.fault) atomicOr(p.fault, c.fault);
     if (k_reads) {
@@ -861,10 +906,10 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
-  // register budget: MINW waves per SIMD (tuning knob THM_EXT_MINW = 2 | 3 | 4)
+  // register budget: MINW waves per SIMD (default 4; tuning knob THM_EXT_MINW = 2 | 3 | 4)
   static const int minw = [] {
     const char* e = getenv("THM_EXT_MINW");
-    const int v = e ? atoi(e) : 2;
+    const int v = e ? atoi(e) : 4;
     return (v == 3 || v == 4) ? v : 2;
   }();
 #define THM_EXT_CASE(C)                                  \

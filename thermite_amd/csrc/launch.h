@@ -109,6 +109,7 @@ struct ExtendParams {
   uint32_t max_read_len;
   uint32_t max_bw;
   uint32_t max_cols;
+  unsigned long long* prof;  // 16 slots of shader clocks per section (THM_PROF builds), else unused
 };
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
 hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream_t s);

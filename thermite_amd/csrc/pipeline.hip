@@ -134,6 +134,7 @@ int enqueue_run(thm_aligner* a) {
   ep.max_read_len = a->max_read_len;
   ep.max_bw = bw_max;
   ep.max_cols = a->max_read_len + bw_max + 2;
+  ep.prof = a->d_counters.as<unsigned long long>() + 2 * THM_N_COUNTERS;
   HIPCHK(a, launch_extend(ep, cpl, blocks_for(a, n, lds), s));
   HIPCHK(a, hipEventRecord(a->ev[3], s));
 

@@ -78,16 +78,24 @@ struct SwgResult {
 // One instruction per step instead of mov-identity + mov_dpp + max.  The two wait
 // states a DPP read needs after a VALU write are in the asm (hipcc pads nothing
 // inside an asm statement).
-#define THM_DPP_MAX_STEP(v, ctrl) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl : "+v"(v))
 __device__ __forceinline__ int wave_excl_max_scan_fast(int v) {
   int r = NEG;
-  asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
-  THM_DPP_MAX_STEP(r, "row_shr:1 row_mask:0xf bank_mask:0xf");
-  THM_DPP_MAX_STEP(r, "row_shr:2 row_mask:0xf bank_mask:0xf");
-  THM_DPP_MAX_STEP(r, "row_shr:4 row_mask:0xf bank_mask:0xf");
-  THM_DPP_MAX_STEP(r, "row_shr:8 row_mask:0xf bank_mask:0xf");
-  THM_DPP_MAX_STEP(r, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-  THM_DPP_MAX_STEP(r, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  asm("s_nop 1\n\t"
+      "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(r)
+      : "v"(v));
   return r;
 }
 
@@ -167,7 +175,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         lane_tot = max(lane_tot, key[c]);
       }
       int run = wave_excl_max_scan_fast(lane_tot);
-      bool improve = false, alive = false;
+      unsigned long long m_imp = 0, m_alive = 0;
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
@@ -187,18 +195,18 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         best = better ? Dn : best;
         best_i = better ? b : best_i;
         best_j = better ? j : best_j;
-        improve = improve || (valid && Dn > run_max);
-        alive = alive || (valid && (Dn + (xlen - b) > run_max));
+        m_imp |= __ballot(valid && Dn > run_max);
+        m_alive |= __ballot(valid && (Dn + (xlen - b) > run_max));
         Dv[c] = valid ? Dn : Dv[c];
         Cv[c] = valid ? Cn[c] : Cv[c];
       }
       tr += CPL * 2;
       res.cells += (unsigned)rows1;
       res.cols += 1;
-      if (__ballot(improve)) run_max += MATCH_SCORE;
+      if (m_imp) run_max += MATCH_SCORE;
       // reference :110: with x_drop >= band_width the X-drop test cannot fire in
       // phase 1; the early exit is ours (see above)
-      if (!__ballot(alive)) {  // (an improving lane is alive by construction)
+      if (!m_alive) {  // (an improving lane is alive by construction)
         finished = true;
         break;
       }
@@ -233,7 +241,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         lane_tot = max(lane_tot, key[c]);
       }
       int run = wave_excl_max_scan_fast(lane_tot);
-      bool improve = false, alive = false, xalive = false;
+      unsigned long long m_imp = 0, m_alive = 0, m_x = 0;
       const int xfloor = run_max - xd;  // tested against the updated run_max below
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
@@ -255,22 +263,20 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         best = better ? Dn : best;
         best_i = better ? i : best_i;
         best_j = better ? j : best_j;
-        improve = improve || (valid && Dn > run_max);
-        // X-drop survivor w.r.t. the updated maximum: if some lane improves, that lane itself survives
-        xalive = xalive || (valid && Dn >= xfloor);
-        alive = alive || (valid && (Dn + (xlen - i) > run_max));
+        m_imp |= __ballot(valid && Dn > run_max);
+        m_x |= __ballot(valid && Dn >= xfloor);  // X-drop survivors (only consulted when nothing improved)
+        m_alive |= __ballot(valid && (Dn + (xlen - i) > run_max));
         Dv[c] = valid ? Dn : Dv[c];
         Cv[c] = Cn[c];
       }
       tr += CPL * 2;
       res.cells += (unsigned)(rows_end - top);
-      const bool any_improve = __ballot(improve) != 0;
-      if (any_improve) {
+      if (m_imp) {
         run_max += MATCH_SCORE;
         continue;  // the improving cell equals the new maximum: neither X-drop nor the early exit can apply
       }
-      if (!__ballot(xalive)) break;  // reference :151  band_max < max_score - x_drop
-      if (!__ballot(alive)) break;   // early exit: the result can no longer change
+      if (!m_x) break;      // reference :151  band_max < max_score - x_drop
+      if (!m_alive) break;  // early exit: the result can no longer change
     }
   }
 

@@ -29,4 +29,13 @@ for name, opts in (("ci", capi.CI_OPTS), ("default", capi.DEFAULT_OPTS)):
     dt = (time.perf_counter() - t0) / K
     print("%-8s ref=%d n=%d  %.2f Mreads/s  wall %.2f ms  " % (name, ref_len, n, n / dt / 1e6, dt * 1e3) +
           " ".join("%s=%.2f" % kv for kv in acc.items()), flush=True)
+    c = dict(zip(capi.COUNTER_NAMES, a.counters().tolist()))
+    runs = K + 2
+    print("         per read: smems %.2f hits %.2f swg_calls %.2f cols %.1f cells %.0f alns %.2f win_bytes %.0f" % tuple(
+        c[k] / (n * runs) for k in ("smems", "hits", "swg_calls", "dp_cols", "dp_cells", "alns", "window_bytes")), flush=True)
+    pr = a.debug_prof()
+    if pr.sum() > 0:
+        names = ["setup", "stage", "dp", "traceback", "tree", "txprep", "lift", "emit", "final", "other"]
+        tot = float(pr[:10].sum())
+        print("         extend sections: " + " ".join("%s=%.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(names, pr[:10])), flush=True)
     a.close()
