@@ -51,7 +51,12 @@ static int get_dev_copy(thm_aligner* a) {
     up(d->txs, ix->txs);
     up(d->exons, ix->exons);
     up(d->exon_txoff, ix->exon_txoff);
-    up(d->tx_seq, ix->tx_seq);
+    // transcript sequences get 16 bytes of front padding: window staging reads whole 16-byte
+    // granules and may start up to 15 bytes before a transcript
+    if (e == hipSuccess) e = d->tx_seq.ensure(ix->tx_seq.size() + 32);
+    if (e == hipSuccess) e = hipMemsetAsync(d->tx_seq.p, '$', 16, s);
+    if (e == hipSuccess && !ix->tx_seq.empty())
+      e = hipMemcpyAsync(d->tx_seq.as<uint8_t>() + 16, ix->tx_seq.data(), ix->tx_seq.size(), hipMemcpyHostToDevice, s);
     up(d->exon_tree, ix->exon_tree);
     up(d->gene_tree, ix->gene_tree);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -69,7 +74,7 @@ static int get_dev_copy(thm_aligner* a) {
     v.txs = d->txs.as<thm_tx>();
     v.exons = d->exons.as<thm_exon>();
     v.exon_txoff = d->exon_txoff.as<uint64_t>();
-    v.tx_seq = d->tx_seq.as<uint8_t>();
+    v.tx_seq = d->tx_seq.as<uint8_t>() + 16;
     v.exon_tree = d->exon_tree.as<TreeNode>();
     v.gene_tree = d->gene_tree.as<TreeNode>();
     v.n = ix->n;

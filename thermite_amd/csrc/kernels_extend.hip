@@ -16,8 +16,9 @@
 // The hits of one read are processed strictly in the reference's order because
 // band_width / x_drop / max_aln_score are loop-carried (src/aligner.rs:143-175).
 // Reads are independent, so the parallelism is: reads over wavefronts, band
-// cells over lanes.  All control flow below is wave-uniform; lane 0 performs the
-// few scalar stores.
+// cells over lanes.  Control flow is wave-uniform and wave-uniform values are kept
+// on the scalar unit (readfirstlane) so that tree nodes, exons and transcript
+// records come through the scalar cache and do not occupy vector registers.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -30,7 +31,6 @@ namespace dev {
 
 constexpr int MAX_YCLIPS = 64;
 enum : int { FAULT_OPS_POOL = 1, FAULT_INTERNAL = 2, FAULT_CONTRACT = 4 };
-constexpr uint8_t OPK_YMARK = 5;
 
 __device__ __forceinline__ uint8_t sanitize_base_e(uint8_t c) {
   if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
@@ -70,19 +70,17 @@ __device__ RefInfo idx_to_ref(const DeviceIndex& ix, uint64_t idx) {
 }
 
 // wave-private LDS carve-up
-template <int CPL>
 struct Wctx {
   uint8_t* rd;   // sanitised read, zero padded
-  uint8_t* win;  // reference / transcript window
+  uint8_t* win;  // reference / transcript window (16-byte aligned copy)
   unsigned long long* trace;
   uint8_t* pa;  // three path buffers (op kinds 0..3), rotated by pointer swap
   uint8_t* pb;
   uint8_t* pc;
-  uint8_t* lifted;  // path with intron markers
-  uint32_t* ycl;    // intron lengths of `lifted`, in order of appearance
-  uint8_t* ser;     // serialised op stream staging
-  int* stack;       // interval-tree traversal stack
-  int L, opcap, sercap, wcap;
+  int* mk_k;      // intron markers of the alignment being emitted: op index they precede ...
+  uint32_t* ycl;  // ... and their lengths
+  int* stack;     // interval-tree traversal stack
+  int L, opcap, wcap;
   unsigned cells, cols, calls, winbytes;
   int fault;
 #ifdef THM_PROF
@@ -113,34 +111,52 @@ struct Path {
   long long ystart, yend;  // in the coordinates r / lo_abs were given in
 };
 
+// One SwgExtend::extend + trace.  The band slots that can ever hold a cell number
+// min(2*bw+1, |x|+1): when that fits 64 the one-cell-per-lane code is exact even
+// inside a kernel compiled for a wider band (slots >= |x|+1 are never valid), and
+// it issues half the instructions per column.
+template <int CPL>
+__device__ __forceinline__ int swg_and_trace(Wctx& c, const uint8_t* xs, int dx, int xlen, const uint8_t* ys, int dy, int ylen,
+                                             int bw, int xd, uint8_t* ops, int stride, int max_ops, SwgResult& r) {
+  int n;
+  if (CPL > 1 && min(2 * bw + 1, xlen + 1) <= 64) {
+    r = swg_extend_wave<1>(xs, dx, xlen, ys, dy, ylen, bw, xd, c.trace);
+    wfence();
+    PROF_MARK(c, PS_DP);
+    n = swg_traceback_wave<1>(c.trace, r.xend, r.yend, bw, ops, stride, max_ops);
+  } else {
+    r = swg_extend_wave<CPL>(xs, dx, xlen, ys, dy, ylen, bw, xd, c.trace);
+    wfence();
+    PROF_MARK(c, PS_DP);
+    n = swg_traceback_wave<CPL>(c.trace, r.xend, r.yend, bw, ops, stride, max_ops);
+  }
+  wfence();
+  PROF_MARK(c, PS_TRACEBACK);
+  return n;
+}
+
 // extend_left_right, reference src/aligner.rs:352-407.  `win` holds ref_seq bytes
 // from absolute coordinate win0; ref_seq itself spans [lo_abs, hi_abs).
 template <int CPL>
-__device__ Path extend_lr(Wctx<CPL>& c, long long win0, long long lo_abs, long long hi_abs, long long r, int q, int len,
-                          int bw, int xd, uint8_t* buf) {
+__device__ Path extend_lr(Wctx& c, long long win0, long long lo_abs, long long hi_abs, long long r, int q, int len, int bw,
+                          int xd, uint8_t* buf) {
   const int L = c.L;
   Path p;
+  PROF_MARK(c, PS_OTHER);
   // right: x = read[q+len..], y = ref_seq[r+len..]   (:360-362)
   const int xr = L - (q + len);
   const long long yr_avail = hi_abs - (r + len);
   const int yr = (int)min(yr_avail, (long long)(xr + bw + 1));
-  PROF_MARK(c, PS_OTHER);
-  const SwgResult R = swg_extend_wave<CPL>(c.rd + q + len, 1, xr, c.win + (r + len - win0), 1, yr, bw, xd, c.trace);
-  wfence();
-  PROF_MARK(c, PS_DP);
-  int nr = swg_traceback_wave<CPL>(c.trace, R.xend, R.yend, bw, buf + c.opcap - 1, -1, c.opcap);
-  wfence();
-  PROF_MARK(c, PS_TRACEBACK);
+  SwgResult R, Lt;
+  int nr = swg_and_trace<CPL>(c, c.rd + q + len, 1, xr, c.win + (r + len - win0), 1, yr, bw, xd, buf + c.opcap - 1, -1,
+                              c.opcap, R);
   // left: both reversed, y = ref_seq[r.saturating_sub(L+bw)..r]   (:364-375)
   const int xl = q;
   const long long rel = r - lo_abs;
   const long long y0 = lo_abs + (rel > (long long)(L + bw) ? rel - (L + bw) : 0);
   const int yl = (int)min(r - y0, (long long)(xl + bw + 1));
-  const SwgResult Lt = swg_extend_wave<CPL>(c.rd + q - 1, -1, xl, c.win + (r - 1 - win0), -1, yl, bw, xd, c.trace);
-  wfence();
-  PROF_MARK(c, PS_DP);
-  int nl = (nr >= 0) ? swg_traceback_wave<CPL>(c.trace, Lt.xend, Lt.yend, bw, buf, 1, c.opcap - nr) : -1;
-  wfence();
+  int nl = swg_and_trace<CPL>(c, c.rd + q - 1, -1, xl, c.win + (r - 1 - win0), -1, yl, bw, xd, buf, 1,
+                              c.opcap - max(nr, 0), Lt);
   c.cells += R.cells + Lt.cells;
   c.cols += R.cols + Lt.cols;
   c.calls += 2;
@@ -170,90 +186,44 @@ __device__ Path extend_lr(Wctx<CPL>& c, long long win0, long long lo_abs, long l
   return p;
 }
 
-// stage [a, b) of a global byte array into c.win
-template <int CPL>
-__device__ void stage_window(Wctx<CPL>& c, const uint8_t* src, long long a, long long b) {
-  const int n = (int)(b - a);
+// Stage [a, b) of a global byte array into c.win with 16-byte loads.  Returns the
+// coordinate that c.win[0] corresponds to (a rounded down to the 16-byte grid of
+// the source address; the arrays carry 16 bytes of padding at both ends of use).
+__device__ long long stage_window(Wctx& c, const uint8_t* src, long long a, long long b) {
+  const unsigned mis = (unsigned)((uintptr_t)(src + a) & 15u);
+  const int n = (int)(b - a) + (int)mis;
   if (n > c.wcap) {
     c.fault |= FAULT_INTERNAL;
-    return;
+    return a;
   }
-  for (int t = lane_id(); t < n; t += 64) c.win[t] = src[a + t];
-  c.winbytes += (unsigned)n;
+  const uint4* g = (const uint4*)(src + a - mis);
+  uint4* w = (uint4*)c.win;
+  for (int t = lane_id(); t * 16 < n; t += 64) w[t] = g[t];
+  c.winbytes += (unsigned)(b - a);
   wfence();
   PROF_MARK(c, PS_STAGE);
+  return a - (long long)mis;
 }
 
-// serialise a path (kinds 0..3, 5 = intron marker) into c.ser; lane 0 writes.
-// Forward: [Xclip(xstart)] path [Xclip(L-xend)]; reverse mirrors the whole list
-// (concat_to_chr_aln on a reverse-strand Ref, src/aligner.rs:440-447).
-template <int CPL>
-__device__ int serialize(Wctx<CPL>& c, const uint8_t* path, int n, int xstart, int xend, bool reverse, int n_y) {
-  const int first = reverse ? (c.L - xend) : xstart;
-  const int last = reverse ? xstart : (c.L - xend);
-  const int total = n + 4 * n_y + (first > 0 ? 5 : 0) + (last > 0 ? 5 : 0);
-  if (total > c.sercap) {
-    c.fault |= FAULT_INTERNAL;
-    return 0;
-  }
-  if (lane_id() == 0) {
-    uint8_t* o = c.ser;
-    int pos = 0;
-    auto put_clip = [&](uint8_t kind, uint32_t v) {
-      o[pos] = kind;
-      o[pos + 1] = (uint8_t)v;
-      o[pos + 2] = (uint8_t)(v >> 8);
-      o[pos + 3] = (uint8_t)(v >> 16);
-      o[pos + 4] = (uint8_t)(v >> 24);
-      pos += 5;
-    };
-    if (first > 0) put_clip(THM_OP_XCLIP, (uint32_t)first);
-    int yk = reverse ? n_y - 1 : 0;
-    for (int k = 0; k < n; k++) {
-      const uint8_t op = path[reverse ? n - 1 - k : k];
-      if (op == OPK_YMARK) {
-        put_clip(THM_OP_YCLIP, c.ycl[yk]);
-        yk += reverse ? -1 : 1;
-      } else {
-        o[pos++] = op;
-      }
-    }
-    if (last > 0) put_clip(THM_OP_XCLIP, (uint32_t)last);
-  }
-  wfence();
-  return total;
-}
-
-// copy c.ser[0..n) into the global op pool; returns the pool offset
-template <int CPL>
-__device__ unsigned long long emit_ops(Wctx<CPL>& c, const ExtendParams& p, int n) {
-  unsigned long long off = 0;
-  if (lane_id() == 0) off = atomicAdd(p.ops_cursor, (unsigned long long)n);
-  off = bcast64(off);
-  if (off + (unsigned long long)n > p.cand_ops_cap) {
-    c.fault |= FAULT_OPS_POOL;
-    return 0;
-  }
-  for (int t = lane_id(); t < n; t += 64) p.cand_ops[off + t] = c.ser[t];
-  return off;
-}
-
-// lift_tx_to_gx, reference src/txome.rs:110-160, on a path without clips.
-// Returns the number of ops written to c.lifted (with OPK_YMARK markers, lengths
-// in c.ycl), sets gx start/end in concatenated coordinates.
-template <int CPL>
-__device__ int lift_tx_to_gx(Wctx<CPL>& c, const DeviceIndex& ix, const thm_tx& tx, const uint8_t* path, int n,
-                             bool trailing_clip, long long ystart, long long yend, long long& gx_ystart,
-                             long long& gx_yend, int& n_y) {
+// lift_tx_to_gx, reference src/txome.rs:110-160, without materialising the lifted
+// list: returns the introns as markers (c.mk_k[m] = index of the path op the
+// Yclip precedes, nops = "after the last op"; c.ycl[m] = its length) and the
+// lifted start / end.  A Yclip is pushed before the first op at which the
+// transcript position has reached an exon end (:133-141); the reference's op list
+// includes a trailing Xclip when the read is clipped on the right, which gets its
+// own loop iteration -- so an alignment that ends exactly on an exon boundary
+// still receives the intron (the edge case noted at src/txome.rs:132).
+__device__ int lift_markers(Wctx& c, const DeviceIndex& ix, const thm_tx& tx, const uint8_t* path, int n, bool trailing_clip,
+                            long long ystart, long long yend, long long& gx_ystart, long long& gx_yend) {
   const thm_exon* ex = ix.exons + tx.exon_begin;
   const uint64_t* toff = ix.exon_txoff + tx.exon_begin;
   const int ne = (int)tx.n_exons;
-  long long i = ystart;
+  const int lane = lane_id();
   // exon where the alignment starts: while exon_sum + len <= i  (:123-126)
-  int lo = 0, hi = ne;  // first e with toff[e] + len(e) > i
+  int lo = 0, hi = ne;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if ((long long)(toff[mid] + (ex[mid].end - ex[mid].start)) <= i)
+    if ((long long)(toff[mid] + (ex[mid].end - ex[mid].start)) <= ystart)
       lo = mid + 1;
     else
       hi = mid;
@@ -262,67 +232,106 @@ __device__ int lift_tx_to_gx(Wctx<CPL>& c, const DeviceIndex& ix, const thm_tx& 
   if (e >= ne) {  // index panic in the reference
     c.fault |= FAULT_CONTRACT;
     gx_ystart = gx_yend = 0;
-    n_y = 0;
     return 0;
   }
   thm_exon cur = ex[e];
   long long exon_sum = (long long)toff[e];
-  gx_ystart = (long long)cur.start + (i - exon_sum);
-  int out = 0;
-  n_y = 0;
-  const int lane = lane_id();
-  for (int k = 0; k < n; k++) {
-    if (e + 1 < ne && exon_sum + (long long)(cur.end - cur.start) <= i) {  // :133-141
-      const thm_exon nxt = ex[e + 1];
-      if (n_y >= MAX_YCLIPS || out >= c.opcap + MAX_YCLIPS) {
-        c.fault |= FAULT_INTERNAL;
-        break;
-      }
-      if (lane == 0) {
-        c.lifted[out] = OPK_YMARK;
-        c.ycl[n_y] = (uint32_t)(nxt.start - cur.end);
-      }
-      out++;
-      n_y++;
-      exon_sum += (long long)(cur.end - cur.start);
-      cur = nxt;
-      e++;
-    }
-    const uint8_t op = (uint8_t)bcast_first((int)path[k]);
-    if (op == OPK_MATCH || op == OPK_SUBST || op == OPK_DEL) i++;
-    if (lane == 0) c.lifted[out] = op;
-    out++;
+  gx_ystart = (long long)cur.start + (ystart - exon_sum);
+  // transcript positions advance on Match / Subst / Del; total must equal yend - ystart (:154)
+  int n_adv = 0;
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    const int k = k0 + lane;
+    const uint8_t op = (k < n) ? path[k] : (uint8_t)OPK_INS;
+    n_adv += __popcll(__ballot(op != OPK_INS));
   }
-  // The reference's op list ends with Xclip(L - xend) when the read is clipped on
-  // the right; that op gets its own loop iteration, so an alignment ending exactly
-  // on an exon boundary still receives the intron (and yend moves to the next
-  // exon's start) -- the "extra exon" edge case noted at src/txome.rs:132.
-  if (trailing_clip && e + 1 < ne && exon_sum + (long long)(cur.end - cur.start) <= i) {
-    const thm_exon nxt = ex[e + 1];
-    if (n_y >= MAX_YCLIPS || out >= c.opcap + MAX_YCLIPS) {
+  if ((long long)n_adv != yend - ystart) c.fault |= FAULT_CONTRACT;
+  int n_y = 0;
+  for (;;) {
+    const long long bnd = exon_sum + (long long)(cur.end - cur.start);  // transcript offset of this exon's end
+    if (e + 1 >= ne || bnd > yend) break;
+    // index of the op that follows the advancing op which brings the position to bnd
+    const int need = (int)(bnd - ystart);  // 1-based rank among advancing ops
+    int kstar = -1, seen = 0;
+    for (int k0 = 0; k0 < n && kstar < 0; k0 += 64) {
+      const int k = k0 + lane;
+      const uint8_t op = (k < n) ? path[k] : (uint8_t)OPK_INS;
+      const unsigned long long m = __ballot(op != OPK_INS);
+      const int cnt = __popcll(m);
+      if (seen + cnt >= need) {
+        const int rank = need - seen;  // rank within this chunk, >= 1
+        const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+        const bool mine = ((m >> lane) & 1ull) && (__popcll(m & le) == rank);
+        const unsigned long long sel = __ballot(mine);
+        kstar = k0 + __builtin_ctzll(sel) + 1;
+      }
+      seen += cnt;
+    }
+    if (kstar < 0) break;                        // cannot happen when n_adv is consistent
+    if (kstar >= n && !trailing_clip) break;     // boundary reached by the very last op: no further iteration
+    if (n_y >= MAX_YCLIPS) {
       c.fault |= FAULT_INTERNAL;
-    } else {
-      if (lane == 0) {
-        c.lifted[out] = OPK_YMARK;
-        c.ycl[n_y] = (uint32_t)(nxt.start - cur.end);
-      }
-      out++;
-      n_y++;
-      exon_sum += (long long)(cur.end - cur.start);
-      cur = nxt;
-      e++;
+      break;
     }
+    const thm_exon nxt = ex[e + 1];
+    if (lane == 0) {
+      c.mk_k[n_y] = kstar;
+      c.ycl[n_y] = (uint32_t)(nxt.start - cur.end);
+    }
+    n_y++;
+    exon_sum = bnd;
+    cur = nxt;
+    e++;
   }
-  if (i != yend) c.fault |= FAULT_CONTRACT;  // assert_eq!(i, tx_aln.yend), :154
-  gx_yend = (long long)cur.start + (i - exon_sum);
+  gx_yend = (long long)cur.start + (yend - exon_sum);
   wfence();
   PROF_MARK(c, PS_LIFT);
-  return out;
+  return n_y;
 }
 
-struct Accepted {
-  int score;
-};
+// Serialise [Xclip(xstart)] path-with-introns [Xclip(L-xend)] straight into the
+// global op pool, every lane writing its own bytes; `reverse` mirrors the whole
+// list (concat_to_chr_aln on a reverse-strand Ref, src/aligner.rs:440-447).
+// Returns the pool offset, byte count in n_bytes.
+__device__ unsigned long long emit_alignment(Wctx& c, const ExtendParams& p, const uint8_t* path, int n, int xstart, int xend,
+                                             bool reverse, int n_y, int& n_bytes) {
+  const int lane = lane_id();
+  const int lead = xstart, trail = c.L - xend;
+  const int lead5 = lead > 0 ? 5 : 0, trail5 = trail > 0 ? 5 : 0;
+  const int total = lead5 + n + 5 * n_y + trail5;
+  n_bytes = total;
+  unsigned long long off = 0;
+  if (lane == 0) off = atomicAdd(p.ops_cursor, (unsigned long long)total);
+  off = bcast64(off);
+  if (off + (unsigned long long)total > p.cand_ops_cap) {
+    c.fault |= FAULT_OPS_POOL;
+    return 0;
+  }
+  uint8_t* o = p.cand_ops + off;
+  auto put5 = [&](int pos, uint8_t kind, uint32_t v) {
+    o[pos] = kind;
+    o[pos + 1] = (uint8_t)v;
+    o[pos + 2] = (uint8_t)(v >> 8);
+    o[pos + 3] = (uint8_t)(v >> 16);
+    o[pos + 4] = (uint8_t)(v >> 24);
+  };
+  // forward byte position of an element; the reversed position is total - (pos + size)
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < n) {
+      int before = 0;
+      for (int m = 0; m < n_y; m++) before += (c.mk_k[m] <= k) ? 1 : 0;
+      const int pos = lead5 + k + 5 * before;
+      o[reverse ? total - (pos + 1) : pos] = path[k];
+    }
+  }
+  if (lane < n_y) {
+    const int pos = lead5 + c.mk_k[lane] + 5 * lane;
+    put5(reverse ? total - (pos + 5) : pos, THM_OP_YCLIP, c.ycl[lane]);
+  }
+  if (lane == 0 && lead > 0) put5(reverse ? total - 5 : 0, THM_OP_XCLIP, (uint32_t)lead);
+  if (lane == 1 && trail > 0) put5(reverse ? 0 : total - 5, THM_OP_XCLIP, (uint32_t)trail);
+  return off;
+}
 
 template <int CPL, int MINW>
 __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
@@ -331,27 +340,23 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   const int wave = (int)(threadIdx.x >> 6);
   // ---- LDS carve (must match extend_lds_bytes) ----
   const uint32_t lcap = (p.max_read_len + 31u) & ~15u;
-  const uint32_t wcap = (2u * (p.max_read_len + p.max_bw) + p.max_read_len + 32u) & ~15u;
+  const uint32_t wcap = (2u * (p.max_read_len + p.max_bw) + p.max_read_len + 48u) & ~15u;
   const uint32_t ycols = p.max_read_len + p.max_bw + 2u;
   const uint32_t trb = (ycols + 1u) * CPL * 16u;
   const uint32_t opcap = (2u * p.max_read_len + 2u * p.max_bw + 31u) & ~15u;
-  const uint32_t liftcap = opcap + 64u;
-  const uint32_t sercap = (opcap + 64u + 5u * (2u + MAX_YCLIPS) + 15u) & ~15u;
-  const uint32_t per_wave = lcap + wcap + trb + 3u * opcap + liftcap + 4u * MAX_YCLIPS + sercap + 256u;
+  const uint32_t per_wave = lcap + wcap + trb + 3u * opcap + 8u * MAX_YCLIPS + 256u;
   uint8_t* base = smem + (size_t)wave * per_wave;
-  Wctx<CPL> c;
+  Wctx c;
   c.rd = base;
   c.win = c.rd + lcap;
   c.trace = (unsigned long long*)(c.win + wcap);
   c.pa = (uint8_t*)c.trace + trb;
   c.pb = c.pa + opcap;
   c.pc = c.pb + opcap;
-  c.lifted = c.pc + opcap;
-  c.ycl = (uint32_t*)(c.lifted + liftcap);
-  c.ser = (uint8_t*)(c.ycl + MAX_YCLIPS);
-  c.stack = (int*)(c.ser + sercap);
+  c.mk_k = (int*)(c.pc + opcap);
+  c.ycl = (uint32_t*)(c.mk_k + MAX_YCLIPS);
+  c.stack = (int*)(c.ycl + MAX_YCLIPS);
   c.opcap = (int)opcap;
-  c.sercap = (int)sercap;
   c.wcap = (int)wcap;
   c.cells = c.cols = c.calls = c.winbytes = 0;
   c.fault = 0;
@@ -415,147 +420,163 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           // ================= align_seed_hit (src/aligner.rs:198-314) =================
           const int bw = band_width, xd = x_drop;
           const RefInfo ref = idx_to_ref(ix, (uint64_t)hr);
-          // genome window (:212-215)
-          const long long rs = (long long)ref.start;
-          const long long seq_start = max((hr > (long long)(L + bw)) ? hr - (L + bw) : 0LL, rs);
-          const long long seq_end = min(hr + len + L + bw, (long long)ref.end - 1);
-          stage_window(c, ix.text, seq_start, seq_end);
-          Path gx = extend_lr(c, seq_start, seq_start, seq_end, hr, q, len, bw, xd, c.pa);
-          uint8_t* gx_path = c.pa;
+          const uint64_t qs = (uint64_t)hr, qe = (uint64_t)(hr + len);  // the seed on the concatenated text
 
-          PROF_MARK(c, PS_OTHER);
-          // transcripts whose exons overlap the seed (:231-258), IntervalTree::find order
+          // One loop runs the genome extension (target 0) and then one extension per
+          // transcript yielded by exon_to_tx.find (:231-258), so that the extension
+          // code is instantiated once.
+          Path gx, best;
+          gx.score = gx.nops = gx.xstart = gx.xend = 0;
+          gx.ystart = gx.yend = 0;
+          best = gx;
           bool have_best = false;
           uint32_t best_tx = 0;
-          Path best;
-          best.score = 0;
-          best.nops = 0;
-          best.xstart = best.xend = 0;
-          best.ystart = best.yend = 0;
           uint8_t* cur_buf = c.pb;
           uint8_t* best_buf = c.pc;
-          {
-            const uint64_t qs = (uint64_t)hr, qe = (uint64_t)(hr + len);
-            int sp = 0;
-            if (ix.exon_root >= 0) {
-              if (lane == 0) c.stack[0] = ix.exon_root;
-              sp = 1;
-            }
-            wfence();
-            bool stop = false;
-            while (sp > 0 && !stop) {
-              const int ni = bcast_first(c.stack[--sp]);  // wave-uniform: the node is fetched through the scalar cache
-              wfence();
-              const TreeNode nd = ix.exon_tree[ni];
-              if (qs < nd.max) {
-                if (nd.left >= 0) {
-                  if (sp >= 62) {
+          int sp = 0;
+          bool genome_done = false;
+          for (;;) {
+            long long win0, lo_abs, hi_abs, t_r;
+            int t_q, t_len;
+            uint8_t* buf;
+            uint32_t tx_idx = 0;
+            if (!genome_done) {
+              // genome window (:212-215)
+              const long long rs = (long long)ref.start;
+              const long long seq_start = max((hr > (long long)(L + bw)) ? hr - (L + bw) : 0LL, rs);
+              const long long seq_end = min(hr + len + L + bw, (long long)ref.end - 1);
+              win0 = stage_window(c, ix.text, seq_start, seq_end);
+              lo_abs = seq_start;
+              hi_abs = seq_end;
+              t_r = hr;
+              t_q = q;
+              t_len = len;
+              buf = c.pa;
+            } else {
+              // next interval IntervalTree::find yields: pop; if q.start < node.max push left;
+              // if q.end > node.start push right and yield on overlap
+              bool found = false;
+              while (sp > 0 && !found) {
+                const int ni = bcast_first(c.stack[--sp]);  // uniform: the node comes through the scalar cache
+                wfence();
+                const TreeNode nd = ix.exon_tree[ni];
+                if (qs < nd.max) {
+                  if (sp >= 60) {
                     c.fault |= FAULT_INTERNAL;
+                    sp = 0;
                     break;
                   }
-                  if (lane == 0) c.stack[sp] = nd.left;
-                  sp++;
-                }
-                if (qe > nd.start) {
-                  if (nd.right >= 0) {
-                    if (sp >= 62) {
-                      c.fault |= FAULT_INTERNAL;
-                      break;
-                    }
-                    if (lane == 0) c.stack[sp] = nd.right;
+                  if (nd.left >= 0) {
+                    if (lane == 0) c.stack[sp] = nd.left;
                     sp++;
                   }
-                  wfence();
-                  if (qs < nd.end && nd.start < qe) {
-                    PROF_MARK(c, PS_TREE);
-                    // ---- one transcript ----
-                    const uint32_t tx_idx = nd.value;
-                    const thm_tx tx = ix.txs[tx_idx];
-                    // lift_mem_to_tx (src/txome.rs:82-103): first exon in transcript order that intersects
-                    int fe = -1;
-                    for (uint32_t e0 = 0; e0 < tx.n_exons && fe < 0; e0 += 64) {
-                      const uint32_t e = e0 + (uint32_t)lane;
-                      bool hit = false;
-                      if (e < tx.n_exons) {
-                        const thm_exon x = ix.exons[tx.exon_begin + e];
-                        const uint64_t a0 = qs, a1 = qe, b0 = x.start, b1 = x.end;
-                        hit = (a0 >= b0 && a0 < b1) || (b0 >= a0 && b0 < a1);
-                      }
-                      const unsigned long long m = __ballot(hit);
-                      if (m) fe = (int)e0 + __builtin_ctzll(m);
+                  if (qe > nd.start) {
+                    if (nd.right >= 0) {
+                      if (lane == 0) c.stack[sp] = nd.right;
+                      sp++;
                     }
-                    if (fe < 0) {  // unreachable!() in the reference
-                      c.fault |= FAULT_CONTRACT;
-                    } else {
-                      const thm_exon x = ix.exons[tx.exon_begin + fe];
-                      const long long exon_sum = (long long)ix.exon_txoff[tx.exon_begin + fe];
-                      const long long xs = (long long)x.start, xe = (long long)x.end;
-                      long long t_r = ((hr > xs) ? hr - xs : 0) + exon_sum;
-                      const long long start_offset = (xs > hr) ? xs - hr : 0;
-                      const long long t_end = min(hr + len, xe) - xs + exon_sum;
-                      int t_q = q + (int)start_offset;
-                      int t_len = (int)(t_end - t_r);
-                      const long long tlen = (long long)tx.seq_len;
-                      // window of the transcript around the lifted seed
-                      const long long ws = (t_r > (long long)(L + bw)) ? t_r - (L + bw) : 0;
-                      const long long we = min(tlen, t_r + t_len + L + bw + 1);
-                      stage_window(c, ix.tx_seq + tx.seq_off, ws, we);
-                      // extend_seed_match (src/aligner.rs:410-426)
-                      {
-                        int ext = 0;
-                        bool done = false;
-                        while (!done) {
-                          const int tt = ext + lane;
-                          const long long rp = t_r + t_len + tt;
-                          const int qp = t_q + t_len + tt;
-                          const bool ok = (rp < tlen) && (qp < L) && (c.win[rp - ws] == c.rd[qp]);
-                          const unsigned long long bad = __ballot(!ok);
-                          if (bad) {
-                            ext += __builtin_ctzll(bad);
-                            done = true;
-                          } else {
-                            ext += 64;
-                          }
-                        }
-                        t_len += ext;
-                        ext = 0;
-                        done = false;
-                        while (!done) {
-                          const int tt = ext + lane + 1;
-                          const long long rp = t_r - tt;
-                          const int qp = t_q - tt;
-                          const bool ok = (rp >= 0) && (qp >= 0) && (c.win[rp - ws] == c.rd[qp]);
-                          const unsigned long long bad = __ballot(!ok);
-                          if (bad) {
-                            ext += __builtin_ctzll(bad);
-                            done = true;
-                          } else {
-                            ext += 64;
-                          }
-                        }
-                        t_r -= ext;
-                        t_q -= ext;
-                        t_len += ext;
-                      }
-                      PROF_MARK(c, PS_TXPREP);
-                      Path ta = extend_lr(c, ws, 0, tlen, t_r, t_q, t_len, bw, xd, cur_buf);
-                      if (!have_best || ta.score > best.score) {  // strictly better (:249)
-                        have_best = true;
-                        best_tx = tx_idx;
-                        best = ta;
-                        uint8_t* tmp = cur_buf;
-                        cur_buf = best_buf;
-                        best_buf = tmp;
-                      }
-                      if (ta.score >= L * MATCH_SCORE) stop = true;  // cannot beat an exact match (:253-257)
+                    if (qs < nd.end && nd.start < qe) {
+                      found = true;
+                      tx_idx = nd.value;
                     }
                   }
                 }
+                wfence();
               }
+              PROF_MARK(c, PS_TREE);
+              if (!found) break;
+              const thm_tx tx = ix.txs[tx_idx];
+              // lift_mem_to_tx (src/txome.rs:82-103): first exon in transcript order that intersects
+              int fe = -1;
+              for (uint32_t e0 = 0; e0 < tx.n_exons && fe < 0; e0 += 64) {
+                const uint32_t e = e0 + (uint32_t)lane;
+                bool hit = false;
+                if (e < tx.n_exons) {
+                  const thm_exon x = ix.exons[tx.exon_begin + e];
+                  hit = (qs >= x.start && qs < x.end) || (x.start >= qs && x.start < qe);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (m) fe = (int)e0 + __builtin_ctzll(m);
+              }
+              if (fe < 0) {  // unreachable!() in the reference
+                c.fault |= FAULT_CONTRACT;
+                continue;
+              }
+              const thm_exon x = ix.exons[tx.exon_begin + fe];
+              const long long exon_sum = (long long)ix.exon_txoff[tx.exon_begin + fe];
+              const long long xs = (long long)x.start, xe = (long long)x.end;
+              t_r = ((hr > xs) ? hr - xs : 0) + exon_sum;
+              const long long start_offset = (xs > hr) ? xs - hr : 0;
+              const long long t_end = min(hr + len, xe) - xs + exon_sum;
+              t_q = q + (int)start_offset;
+              t_len = (int)(t_end - t_r);
+              const long long tlen = (long long)tx.seq_len;
+              // window of the transcript around the lifted seed
+              const long long ws = (t_r > (long long)(L + bw)) ? t_r - (L + bw) : 0;
+              const long long we = min(tlen, t_r + t_len + L + bw + 1);
+              win0 = stage_window(c, ix.tx_seq + tx.seq_off, ws, we);
+              // extend_seed_match (src/aligner.rs:410-426): ballots of the first mismatch
+              {
+                int ext = 0;
+                for (bool done = false; !done;) {
+                  const int tt = ext + lane;
+                  const long long rp = t_r + t_len + tt;
+                  const int qp = t_q + t_len + tt;
+                  const bool ok = (rp < tlen) && (qp < L) && (c.win[rp - win0] == c.rd[qp]);
+                  const unsigned long long bad = __ballot(!ok);
+                  if (bad) {
+                    ext += __builtin_ctzll(bad);
+                    done = true;
+                  } else {
+                    ext += 64;
+                  }
+                }
+                t_len += ext;
+                ext = 0;
+                for (bool done = false; !done;) {
+                  const int tt = ext + lane + 1;
+                  const long long rp = t_r - tt;
+                  const int qp = t_q - tt;
+                  const bool ok = (rp >= 0) && (qp >= 0) && (c.win[rp - win0] == c.rd[qp]);
+                  const unsigned long long bad = __ballot(!ok);
+                  if (bad) {
+                    ext += __builtin_ctzll(bad);
+                    done = true;
+                  } else {
+                    ext += 64;
+                  }
+                }
+                t_r -= ext;
+                t_q -= ext;
+                t_len += ext;
+              }
+              lo_abs = 0;
+              hi_abs = tlen;
+              buf = cur_buf;
+              PROF_MARK(c, PS_TXPREP);
+            }
+            const Path pth = extend_lr<CPL>(c, win0, lo_abs, hi_abs, t_r, t_q, t_len, bw, xd, buf);
+            if (!genome_done) {
+              gx = pth;
+              genome_done = true;
+              if (ix.exon_root >= 0) {
+                if (lane == 0) c.stack[0] = ix.exon_root;
+                sp = 1;
+              }
+              wfence();
+            } else {
+              if (!have_best || pth.score > best.score) {  // strictly better (:249)
+                have_best = true;
+                best_tx = tx_idx;
+                best = pth;
+                uint8_t* tmp = cur_buf;
+                cur_buf = best_buf;
+                best_buf = tmp;
+              }
+              if (pth.score >= L * MATCH_SCORE) break;  // cannot beat an exact match (:253-257)
             }
           }
 
-          PROF_MARK(c, PS_TREE);
           // ---- exonic vs unspliced (:263-313) ----
           int aln_type;
           uint32_t type_idx = THM_NO_IDX;
@@ -563,49 +584,56 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           const uint8_t* g_path;
           int g_n, g_ny = 0;
           int sc, xs_, xe_;
-          if (have_best && best.score >= gx.score) {
-            const thm_tx tx = ix.txs[best_tx];
-            g_n = lift_tx_to_gx(c, ix, tx, best_buf, best.nops, best.xend < L, best.ystart, best.yend, cy0, cy1, g_ny);
-            g_path = c.lifted;
+          const bool exonic = have_best && best.score >= gx.score;
+          if (exonic) {
+            g_path = best_buf;
+            g_n = best.nops;
             aln_type = THM_ALN_EXONIC;
             type_idx = best_tx;
             sc = best.score;
             xs_ = best.xstart;
             xe_ = best.xend;
+            cy0 = cy1 = 0;  // set by the lift below, only if the alignment is kept
           } else {
             cy0 = gx.ystart;
             cy1 = gx.yend;
-            g_path = gx_path;
+            g_path = c.pa;
             g_n = gx.nops;
             sc = gx.score;
             xs_ = gx.xstart;
             xe_ = gx.xend;
             aln_type = THM_ALN_INTERGENIC;
-            if (intron_mode) {
-              // first interval gene_intervals.find yields (:283-288, :306)
-              const uint64_t qs = (uint64_t)cy0, qe = (uint64_t)cy1;
-              int sp = 0;
+          }
+          // ================= back in align_read's loop (:146-174) =================
+          bool accept = intron_mode || exonic;
+          if (sc < p.opts.min_aln_score || sc < min_aln_score || sc < max_aln_score - range) accept = false;
+          if (accept) {
+            if (exonic) {
+              g_ny = lift_markers(c, ix, ix.txs[best_tx], best_buf, best.nops, best.xend < L, best.ystart, best.yend, cy0, cy1);
+            } else {
+              // first interval gene_intervals.find yields (:283-288, :306); only reached in intron mode
+              const uint64_t gs = (uint64_t)cy0, ge_ = (uint64_t)cy1;
+              int gsp = 0;
               if (ix.gene_root >= 0) {
                 if (lane == 0) c.stack[0] = ix.gene_root;
-                sp = 1;
+                gsp = 1;
               }
               wfence();
-              while (sp > 0) {
-                const int ni = bcast_first(c.stack[--sp]);
+              while (gsp > 0) {
+                const int ni = bcast_first(c.stack[--gsp]);
                 wfence();
                 const TreeNode nd = ix.gene_tree[ni];
-                if (qs < nd.max) {
-                  if (nd.left >= 0 && sp < 62) {
-                    if (lane == 0) c.stack[sp] = nd.left;
-                    sp++;
+                if (gs < nd.max) {
+                  if (nd.left >= 0 && gsp < 60) {
+                    if (lane == 0) c.stack[gsp] = nd.left;
+                    gsp++;
                   }
-                  if (qe > nd.start) {
-                    if (nd.right >= 0 && sp < 62) {
-                      if (lane == 0) c.stack[sp] = nd.right;
-                      sp++;
+                  if (ge_ > nd.start) {
+                    if (nd.right >= 0 && gsp < 60) {
+                      if (lane == 0) c.stack[gsp] = nd.right;
+                      gsp++;
                     }
-                    wfence();
-                    if (qs < nd.end && nd.start < qe) {
+                    if (gs < nd.end && nd.start < ge_) {
                       aln_type = THM_ALN_INTRONIC;
                       type_idx = nd.value;
                       break;
@@ -614,13 +642,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
                 }
                 wfence();
               }
+              PROF_MARK(c, PS_TREE);
             }
-          }
-          PROF_MARK(c, PS_TREE);
-          // ================= back in align_read's loop (:146-174) =================
-          bool accept = intron_mode || aln_type == THM_ALN_EXONIC;
-          if (sc < p.opts.min_aln_score || sc < min_aln_score || sc < max_aln_score - range) accept = false;
-          if (accept) {
             // concat_to_chr_aln (:429-449)
             const RefInfo cref = idx_to_ref(ix, (uint64_t)cy0);
             uint64_t ch0, ch1;
@@ -634,14 +657,10 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               ch1 = cref.len - ((uint64_t)cy0 - cref.start);
               rev = true;
             }
-            const int nb = serialize(c, g_path, g_n, xs_, xe_, rev, g_ny);
-            const unsigned long long off = emit_ops(c, p, nb);
+            int nb = 0, tnb = 0;
+            const unsigned long long off = emit_alignment(c, p, g_path, g_n, xs_, xe_, rev, g_ny, nb);
             unsigned long long toff2 = 0;
-            int tnb = 0;
-            if (aln_type == THM_ALN_EXONIC) {
-              tnb = serialize(c, best_buf, best.nops, best.xstart, best.xend, false, 0);
-              toff2 = emit_ops(c, p, tnb);
-            }
+            if (exonic) toff2 = emit_alignment(c, p, best_buf, best.nops, best.xstart, best.xend, false, 0, tnb);
             if (n_acc >= n_hits_cap) {
               c.fault |= FAULT_INTERNAL;
             } else if (lane == 0) {
@@ -666,7 +685,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               cd.tx_ops_len = 0;
               cd.tx_score = 0;
               cd.tx_xstart = cd.tx_xend = 0;
-              if (aln_type == THM_ALN_EXONIC) {
+              if (exonic) {
                 cd.tx_ystart = (uint64_t)best.ystart;
                 cd.tx_yend = (uint64_t)best.yend;
                 cd.tx_ylen = ix.txs[best_tx].seq_len;
@@ -886,13 +905,11 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
 
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
   const uint32_t lcap = (max_read_len + 31u) & ~15u;
-  const uint32_t wcap = (2u * (max_read_len + max_bw) + max_read_len + 32u) & ~15u;
+  const uint32_t wcap = (2u * (max_read_len + max_bw) + max_read_len + 48u) & ~15u;
   const uint32_t ycols = max_read_len + max_bw + 2u;
   const uint32_t trb = (ycols + 1u) * cpl * 16u;
   const uint32_t opcap = (2u * max_read_len + 2u * max_bw + 31u) & ~15u;
-  const uint32_t liftcap = opcap + 64u;
-  const uint32_t sercap = (opcap + 64u + 5u * (2u + dev::MAX_YCLIPS) + 15u) & ~15u;
-  const uint32_t per_wave = lcap + wcap + trb + 3u * opcap + liftcap + 4u * dev::MAX_YCLIPS + sercap + 256u;
+  const uint32_t per_wave = lcap + wcap + trb + 3u * opcap + 8u * dev::MAX_YCLIPS + 256u;
   return 4 * (size_t)per_wave;
 }
 
