@@ -132,7 +132,8 @@ inline int base_code(uint8_t c) {
 void build_lut(thm_index* ix) {
   const uint64_t n = ix->n;
   uint32_t kt = 1;
-  while (kt < 13 && (1ull << (2 * (kt + 1))) <= n / 2) kt++;
+  // about one suffix per occupied bucket: 4^kt <= 4n, at most 14 (2 GiB of 8-byte entries)
+  while (kt < 14 && (1ull << (2 * (kt + 1))) <= 4 * n) kt++;
   ix->kt = kt;
   const uint64_t nk = 1ull << (2 * kt);
   ix->lut.assign(nk, LutEntry{0, 0});

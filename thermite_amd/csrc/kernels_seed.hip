@@ -45,7 +45,35 @@ __device__ __forceinline__ uint64_t load8_lds(const uint8_t* base16, int off) {
   return sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
 }
 
-// longest match of rd[pos..L) in the text: length d and suffix-array interval
+// LCP of the query tail rd[qoff..L) with the text at tp, 8 bytes per step; *less
+// tells whether the text suffix sorts before the query (a suffix that has the whole
+// query tail as a prefix is >= it).  At most `cap` characters are compared.
+__device__ __forceinline__ int lcp_cmp(const uint8_t* tp, const uint8_t* rd, int qoff, int cap, bool* less) {
+  int o = 0;
+  *less = false;
+  while (o < cap) {
+    const uint64_t tw = load8_global(tp + o), qw = load8_lds(rd, qoff + o);
+    const uint64_t x = tw ^ qw;
+    if (x) {
+      const int idx = __builtin_ctzll(x) >> 3;
+      if (o + idx < cap) {
+        *less = ((tw >> (8 * idx)) & 0xff) < ((qw >> (8 * idx)) & 0xff);
+        return o + idx;
+      }
+      return cap;
+    }
+    o += 8;
+  }
+  return cap;
+}
+
+// longest match of rd[pos..L) in the text: length d and suffix-array interval.
+//   1. kt-mer table: interval of the first kt characters in one probe;
+//   2. one suffix left -> compare along the text;
+//   3. otherwise: lower bound of the whole query tail among the interval's suffixes
+//      (string comparison from offset d), the longest match is the better of the two
+//      neighbours of the insertion point, and the final interval is found by two
+//      more binary searches on "shares >= ms characters".
 __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int pos, int k, int& out_d, uint32_t& out_lo,
                           uint32_t& out_hi) {
   uint32_t lo = 0, hi = (uint32_t)ix.n;
@@ -66,43 +94,54 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
       d = kt;
     }
   }
-  while (lo < hi && pos + d < L) {
+  if (lo < hi && pos + d < L) {
+    const int cap = L - (pos + d);
+    bool less;
     if (hi - lo == 1) {
-      // a single suffix left: compare along the text 8 bytes at a time
-      const uint8_t* tp = ix.text + ix.sa[lo];
-      for (;;) {
-        const int rem = L - (pos + d);
-        if (rem <= 0) break;
-        const uint64_t x = load8_global(tp + d) ^ load8_lds(rd, pos + d);
-        int m = x ? (__builtin_ctzll(x) >> 3) : 8;
-        m = min(m, rem);
-        d += m;
-        if (m < 8) break;
+      d += lcp_cmp(ix.text + ix.sa[lo] + d, rd, pos + d, cap, &less);
+    } else if (rd[pos + d] != 0) {  // a byte outside ACGTN matches nothing: the interval stays at depth d
+      uint32_t a = lo, b = hi;
+      while (a < b) {
+        const uint32_t m = a + ((b - a) >> 1);
+        (void)lcp_cmp(ix.text + ix.sa[m] + d, rd, pos + d, cap, &less);
+        if (less)
+          a = m + 1;
+        else
+          b = m;
       }
-      break;
+      int l1 = -1, l2 = -1;
+      if (a > lo) l1 = lcp_cmp(ix.text + ix.sa[a - 1] + d, rd, pos + d, cap, &less);
+      if (a < hi) l2 = lcp_cmp(ix.text + ix.sa[a] + d, rd, pos + d, cap, &less);
+      const int ms = max(l1, l2);
+      if (ms > 0) {
+        uint32_t nlo = a, nhi = a;
+        if (l1 >= ms) {  // leftmost suffix in [lo, a) that still shares ms characters
+          uint32_t x = lo, y = a - 1;
+          while (x < y) {
+            const uint32_t m = x + ((y - x) >> 1);
+            if (lcp_cmp(ix.text + ix.sa[m] + d, rd, pos + d, ms, &less) >= ms)
+              y = m;
+            else
+              x = m + 1;
+          }
+          nlo = x;
+        }
+        if (l2 >= ms) {  // one past the rightmost suffix in [a, hi) that shares ms characters
+          uint32_t x = a + 1, y = hi;
+          while (x < y) {
+            const uint32_t m = x + ((y - x) >> 1);
+            if (lcp_cmp(ix.text + ix.sa[m] + d, rd, pos + d, ms, &less) >= ms)
+              x = m + 1;
+            else
+              y = m;
+          }
+          nhi = x;
+        }
+        lo = nlo;
+        hi = nhi;
+        d += ms;
+      }
     }
-    const uint8_t c = rd[pos + d];
-    uint32_t a = lo, b = hi;
-    while (a < b) {
-      const uint32_t m = a + ((b - a) >> 1);
-      if (ix.text[(uint64_t)ix.sa[m] + d] < c)
-        a = m + 1;
-      else
-        b = m;
-    }
-    const uint32_t nlo = a;
-    b = hi;
-    while (a < b) {
-      const uint32_t m = a + ((b - a) >> 1);
-      if (ix.text[(uint64_t)ix.sa[m] + d] <= c)
-        a = m + 1;
-      else
-        b = m;
-    }
-    if (a == nlo) break;
-    lo = nlo;
-    hi = a;
-    d++;
   }
   out_d = (lo < hi) ? d : 0;
   out_lo = lo;

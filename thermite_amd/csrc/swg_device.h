@@ -299,11 +299,13 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
 // path out in either direction).  Returns the number of ops, or -1 on an
 // inconsistent trace.
 //
-// The walk is a serial dependency chain, so it is kept off the memory pipes:
-// the ballot words of 64 consecutive columns are loaded into registers at once
-// (lane t holds column jhi - t), each step picks its word with v_readlane and
-// does the bit test on the scalar unit, and the ops are collected with
-// v_writelane and flushed to LDS 64 at a time.
+// The walk is a serial dependency chain in the reference.  Here the ballot words
+// of 64 consecutive columns are held in registers (lane t holds column jhi - t)
+// and a whole diagonal run is resolved at once: every lane assumes the path
+// reaches its column along the current diagonal, reads its own cell's direction,
+// and one ballot tells how many consecutive lanes really continue diagonally.
+// Those lanes store their Match/Subst ops together; only gap steps are taken one
+// at a time.  An alignment is typically a handful of runs.
 template <int CPL>
 __device__ int swg_traceback_wave(const unsigned long long* trace, int i, int j, int bw, uint8_t* ops, int stride,
                                   int max_ops) {
@@ -313,67 +315,71 @@ __device__ int swg_traceback_wave(const unsigned long long* trace, int i, int j,
   bw = bcast_first(bw);
   int n = 0;
   int jhi = -1;
-  int w_ll[CPL], w_lh[CPL], w_hl[CPL], w_hh[CPL];  // lo/hi ballot words split in 32-bit halves
+  unsigned long long w_lo[CPL], w_hi[CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; c++) w_ll[c] = w_lh[c] = w_hl[c] = w_hh[c] = 0;
-  int acc = 0;  // lane (n & 63) holds op n of the current group of 64
+  for (int c = 0; c < CPL; c++) w_lo[c] = w_hi[c] = 0;
   while (i > 0 || j > 0) {
-    int op;
-    if (j == 0) {
-      op = OPK_INS;  // column 0 is all Ins (reference :65,:70)
-    } else {
-      if (jhi < 0 || j < jhi - 63) {
-        jhi = j;
-        const int col = j - lane;
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-          unsigned long long lo = 0, hi = 0;
-          if (col >= 1) {
-            lo = trace[((size_t)col * CPL + c) * 2 + 0];
-            hi = trace[((size_t)col * CPL + c) * 2 + 1];
-          }
-          w_ll[c] = (int)(unsigned)lo;
-          w_lh[c] = (int)(unsigned)(lo >> 32);
-          w_hl[c] = (int)(unsigned)hi;
-          w_hh[c] = (int)(unsigned)(hi >> 32);
-        }
-      }
-      const int t = jhi - j;
-      const int top = max(j - bw, 0);
-      const int b = i - top;
-      if (b < 0 || b >= 64 * CPL) return -1;
-      const int l = b / CPL, c = b % CPL;
-      unsigned wl = 0, wh = 0;
-#pragma unroll
-      for (int cc = 0; cc < CPL; cc++) {
-        if (c == cc) {
-          if (l < 32) {
-            wl = (unsigned)__builtin_amdgcn_readlane(w_ll[cc], t);
-            wh = (unsigned)__builtin_amdgcn_readlane(w_hl[cc], t);
-          } else {
-            wl = (unsigned)__builtin_amdgcn_readlane(w_lh[cc], t);
-            wh = (unsigned)__builtin_amdgcn_readlane(w_hh[cc], t);
-          }
-        }
-      }
-      const int lb = l & 31;
-      op = (int)((wl >> lb) & 1u) | ((int)((wh >> lb) & 1u) << 1);
+    if (j == 0) {  // column 0 is all Ins (reference :65,:70): i more insertions
+      if (n + i > max_ops) return -1;
+      for (int s = lane; s < i; s += 64) ops[(n + s) * stride] = (uint8_t)OPK_INS;
+      n += i;
+      break;
     }
+    if (jhi < 0 || j < jhi - 63) {
+      jhi = j;
+      const int col = j - lane;
+#pragma unroll
+      for (int c = 0; c < CPL; c++) {
+        unsigned long long lo = 0, hi = 0;
+        if (col >= 1) {
+          lo = trace[((size_t)col * CPL + c) * 2 + 0];
+          hi = trace[((size_t)col * CPL + c) * 2 + 1];
+        }
+        w_lo[c] = lo;
+        w_hi[c] = hi;
+      }
+    }
+    const int t0 = jhi - j;
+    // hypothesis: the path runs diagonally from (i, j); this lane looks at (i - s, j - s)
+    const int s = lane - t0;
+    const int ii = i - s, jj = j - s;
+    const int top = max(jj - bw, 0);
+    const int b = ii - top;
+    const bool cell_ok = (s >= 0) && (jj >= 1) && (ii >= 0) && (b >= 0) && (b < 64 * CPL);
+    const int bb = cell_ok ? b : 0;
+    const int l = bb / CPL, cc = bb % CPL;
+    unsigned long long wl = w_lo[0], wh = w_hi[0];
+#pragma unroll
+    for (int c = 1; c < CPL; c++) {
+      wl = (cc == c) ? w_lo[c] : wl;
+      wh = (cc == c) ? w_hi[c] : wh;
+    }
+    const int dir = (int)((wl >> l) & 1ull) | ((int)((wh >> l) & 1ull) << 1);
+    const unsigned long long okm = __ballot(cell_ok);
+    if (!((okm >> t0) & 1ull)) return -1;
+    const unsigned long long dm = __ballot(cell_ok && ii >= 1 && dir <= OPK_SUBST) >> t0;
+    int run = (~dm == 0ull) ? 64 : __builtin_ctzll(~dm);
+    run = min(run, 64 - t0);
+    if (run > 0) {
+      if (n + run > max_ops) return -1;
+      if (s >= 0 && s < run) ops[(n + s) * stride] = (uint8_t)dir;
+      n += run;
+      i -= run;
+      j -= run;
+      continue;
+    }
+    const int op = __builtin_amdgcn_readlane(dir, t0);
+    if (op <= OPK_SUBST) return -1;  // a diagonal move out of row 0
     if (n >= max_ops) return -1;
-    acc = (lane == (n & 63)) ? op : acc;
+    if (lane == 0) ops[n * stride] = (uint8_t)op;
     n++;
-    if ((n & 63) == 0) ops[(n - 64 + lane) * stride] = (uint8_t)acc;
-    if (op == OPK_MATCH || op == OPK_SUBST) {
-      i--;
-      j--;
-    } else if (op == OPK_INS) {
+    if (op == OPK_INS) {
+      if (i == 0) return -1;
       i--;
     } else {
       j--;
     }
-    if (i < 0 || j < 0) return -1;
   }
-  if ((n & 63) != 0 && lane < (n & 63)) ops[((n & ~63) + lane) * stride] = (uint8_t)acc;
   return n;
 }
 
