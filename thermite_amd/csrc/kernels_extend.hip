@@ -42,29 +42,29 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
 __device__ __forceinline__ void wfence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 struct RefInfo {
-  uint64_t start, end, len;
+  uint32_t start, end, len;  // text < 2^31 symbols in this build: 32-bit coordinates keep the scalar unit usable
   uint32_t id;
   uint32_t name_rank;
   bool strand;
 };
 // Index::idx_to_ref: refs.partition_point(|x| x.end_idx <= idx)
-__device__ RefInfo idx_to_ref(const DeviceIndex& ix, uint64_t idx) {
+__device__ RefInfo idx_to_ref(const DeviceIndex& ix, uint32_t idx) {
   uint32_t lo = 0, hi = ix.n_refs;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (ix.refs[mid].end_idx <= idx)
+    if ((uint32_t)uload(&ix.refs[mid].end_idx) <= idx)
       lo = mid + 1;
     else
       hi = mid;
   }
   if (lo >= ix.n_refs) lo = ix.n_refs - 1;
-  const thm_ref r = ix.refs[lo];
+  const thm_ref r = uload(&ix.refs[lo]);
   RefInfo o;
-  o.start = r.start_idx;
-  o.end = r.end_idx;
-  o.len = r.len;
+  o.start = (uint32_t)r.start_idx;
+  o.end = (uint32_t)r.end_idx;
+  o.len = (uint32_t)r.len;
   o.id = lo;
-  o.name_rank = ix.name_rank[lo];
+  o.name_rank = uload(&ix.name_rank[lo]);
   o.strand = r.strand != 0;
   return o;
 }
@@ -108,7 +108,7 @@ enum { PS_SETUP = 0, PS_STAGE = 1, PS_DP = 2, PS_TRACEBACK = 3, PS_TREE = 4, PS_
 
 struct Path {
   int score, xstart, xend, nops;
-  long long ystart, yend;  // in the coordinates r / lo_abs were given in
+  int ystart, yend;  // in the coordinates r / lo_abs were given in
 };
 
 // One SwgExtend::extend + trace.  The band slots that can ever hold a cell number
@@ -138,23 +138,22 @@ __device__ __forceinline__ int swg_and_trace(Wctx& c, const uint8_t* xs, int dx,
 // extend_left_right, reference src/aligner.rs:352-407.  `win` holds ref_seq bytes
 // from absolute coordinate win0; ref_seq itself spans [lo_abs, hi_abs).
 template <int CPL>
-__device__ Path extend_lr(Wctx& c, long long win0, long long lo_abs, long long hi_abs, long long r, int q, int len, int bw,
-                          int xd, uint8_t* buf) {
+__device__ Path extend_lr(Wctx& c, int win0, int lo_abs, int hi_abs, int r, int q, int len, int bw, int xd, uint8_t* buf) {
   const int L = c.L;
   Path p;
   PROF_MARK(c, PS_OTHER);
   // right: x = read[q+len..], y = ref_seq[r+len..]   (:360-362)
   const int xr = L - (q + len);
-  const long long yr_avail = hi_abs - (r + len);
-  const int yr = (int)min(yr_avail, (long long)(xr + bw + 1));
+  const int yr_avail = hi_abs - (r + len);
+  const int yr = min(yr_avail, xr + bw + 1);
   SwgResult R, Lt;
   int nr = swg_and_trace<CPL>(c, c.rd + q + len, 1, xr, c.win + (r + len - win0), 1, yr, bw, xd, buf + c.opcap - 1, -1,
                               c.opcap, R);
   // left: both reversed, y = ref_seq[r.saturating_sub(L+bw)..r]   (:364-375)
   const int xl = q;
-  const long long rel = r - lo_abs;
-  const long long y0 = lo_abs + (rel > (long long)(L + bw) ? rel - (L + bw) : 0);
-  const int yl = (int)min(r - y0, (long long)(xl + bw + 1));
+  const int rel = r - lo_abs;
+  const int y0 = lo_abs + (rel > L + bw ? rel - (L + bw) : 0);
+  const int yl = min(r - y0, xl + bw + 1);
   int nl = swg_and_trace<CPL>(c, c.rd + q - 1, -1, xl, c.win + (r - 1 - win0), -1, yl, bw, xd, buf, 1,
                               c.opcap - max(nr, 0), Lt);
   c.cells += R.cells + Lt.cells;
@@ -167,7 +166,9 @@ __device__ Path extend_lr(Wctx& c, long long win0, long long lo_abs, long long h
   }
   const int lane = lane_id();
   // rev(left.ops) ++ Match x len ++ right.ops   (:388-394); the clips are implied by xstart / xend
+  #pragma unroll 1
   for (int t = lane; t < len; t += 64) buf[nl + t] = OPK_MATCH;
+  #pragma unroll 1
   for (int t0 = 0; t0 < nr; t0 += 64) {
     const int t = t0 + lane;
     uint8_t v = 0;
@@ -189,9 +190,9 @@ __device__ Path extend_lr(Wctx& c, long long win0, long long lo_abs, long long h
 // Stage [a, b) of a global byte array into c.win with 16-byte loads.  Returns the
 // coordinate that c.win[0] corresponds to (a rounded down to the 16-byte grid of
 // the source address; the arrays carry 16 bytes of padding at both ends of use).
-__device__ long long stage_window(Wctx& c, const uint8_t* src, long long a, long long b) {
+__device__ int stage_window(Wctx& c, const uint8_t* src, int a, int b) {
   const unsigned mis = (unsigned)((uintptr_t)(src + a) & 15u);
-  const int n = (int)(b - a) + (int)mis;
+  const int n = (b - a) + (int)mis;
   if (n > c.wcap) {
     c.fault |= FAULT_INTERNAL;
     return a;
@@ -202,7 +203,7 @@ __device__ long long stage_window(Wctx& c, const uint8_t* src, long long a, long
   c.winbytes += (unsigned)(b - a);
   wfence();
   PROF_MARK(c, PS_STAGE);
-  return a - (long long)mis;
+  return a - (int)mis;
 }
 
 // lift_tx_to_gx, reference src/txome.rs:110-160, without materialising the lifted
@@ -214,7 +215,7 @@ __device__ long long stage_window(Wctx& c, const uint8_t* src, long long a, long
 // own loop iteration -- so an alignment that ends exactly on an exon boundary
 // still receives the intron (the edge case noted at src/txome.rs:132).
 __device__ int lift_markers(Wctx& c, const DeviceIndex& ix, const thm_tx& tx, const uint8_t* path, int n, bool trailing_clip,
-                            long long ystart, long long yend, long long& gx_ystart, long long& gx_yend) {
+                            int ystart, int yend, int& gx_ystart, int& gx_yend) {
   const thm_exon* ex = ix.exons + tx.exon_begin;
   const uint64_t* toff = ix.exon_txoff + tx.exon_begin;
   const int ne = (int)tx.n_exons;
@@ -223,7 +224,8 @@ __device__ int lift_markers(Wctx& c, const DeviceIndex& ix, const thm_tx& tx, co
   int lo = 0, hi = ne;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if ((long long)(toff[mid] + (ex[mid].end - ex[mid].start)) <= ystart)
+    const thm_exon xm = uload(&ex[mid]);
+    if ((int)(uload(&toff[mid]) + (xm.end - xm.start)) <= ystart)
       lo = mid + 1;
     else
       hi = mid;
@@ -234,23 +236,24 @@ __device__ int lift_markers(Wctx& c, const DeviceIndex& ix, const thm_tx& tx, co
     gx_ystart = gx_yend = 0;
     return 0;
   }
-  thm_exon cur = ex[e];
-  long long exon_sum = (long long)toff[e];
-  gx_ystart = (long long)cur.start + (ystart - exon_sum);
+  thm_exon cur = uload(&ex[e]);
+  int exon_sum = (int)uload(&toff[e]);
+  gx_ystart = (int)cur.start + (ystart - exon_sum);
   // transcript positions advance on Match / Subst / Del; total must equal yend - ystart (:154)
   int n_adv = 0;
+  #pragma unroll 1
   for (int k0 = 0; k0 < n; k0 += 64) {
     const int k = k0 + lane;
     const uint8_t op = (k < n) ? path[k] : (uint8_t)OPK_INS;
     n_adv += __popcll(__ballot(op != OPK_INS));
   }
-  if ((long long)n_adv != yend - ystart) c.fault |= FAULT_CONTRACT;
+  if (n_adv != yend - ystart) c.fault |= FAULT_CONTRACT;
   int n_y = 0;
   for (;;) {
-    const long long bnd = exon_sum + (long long)(cur.end - cur.start);  // transcript offset of this exon's end
+    const int bnd = exon_sum + (int)(cur.end - cur.start);  // transcript offset of this exon's end
     if (e + 1 >= ne || bnd > yend) break;
     // index of the op that follows the advancing op which brings the position to bnd
-    const int need = (int)(bnd - ystart);  // 1-based rank among advancing ops
+    const int need = bnd - ystart;  // 1-based rank among advancing ops
     int kstar = -1, seen = 0;
     for (int k0 = 0; k0 < n && kstar < 0; k0 += 64) {
       const int k = k0 + lane;
@@ -272,7 +275,7 @@ __device__ int lift_markers(Wctx& c, const DeviceIndex& ix, const thm_tx& tx, co
       c.fault |= FAULT_INTERNAL;
       break;
     }
-    const thm_exon nxt = ex[e + 1];
+    const thm_exon nxt = uload(&ex[e + 1]);
     if (lane == 0) {
       c.mk_k[n_y] = kstar;
       c.ycl[n_y] = (uint32_t)(nxt.start - cur.end);
@@ -282,7 +285,7 @@ __device__ int lift_markers(Wctx& c, const DeviceIndex& ix, const thm_tx& tx, co
     cur = nxt;
     e++;
   }
-  gx_yend = (long long)cur.start + (yend - exon_sum);
+  gx_yend = (int)cur.start + (yend - exon_sum);
   wfence();
   PROF_MARK(c, PS_LIFT);
   return n_y;
@@ -315,6 +318,7 @@ __device__ unsigned long long emit_alignment(Wctx& c, const ExtendParams& p, con
     o[pos + 4] = (uint8_t)(v >> 24);
   };
   // forward byte position of an element; the reversed position is total - (pos + size)
+  #pragma unroll 1
   for (int k0 = 0; k0 < n; k0 += 64) {
     const int k = k0 + lane;
     if (k < n) {
@@ -337,7 +341,7 @@ template <int CPL, int MINW>
 __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
   // ---- LDS carve (must match extend_lds_bytes) ----
   const uint32_t lcap = (p.max_read_len + 31u) & ~15u;
   const uint32_t wcap = (2u * (p.max_read_len + p.max_bw) + p.max_read_len + 48u) & ~15u;
@@ -374,9 +378,10 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
     if (lane == 0) idx = atomicAdd(p.queue, 1u);
     idx = (unsigned)bcast_first((int)idx);
     if (idx >= p.reads.n_reads) break;
-    const uint64_t r0 = p.reads.offsets[idx];
-    const int L = (int)(p.reads.offsets[idx + 1] - r0);
+    const uint64_t r0 = uload(&p.reads.offsets[idx]);
+    const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
     c.L = L;
+    #pragma unroll 1
     for (int t = lane; t < (int)lcap; t += 64) c.rd[t] = (t < L) ? sanitize_base_e(p.reads.bases[r0 + t]) : (uint8_t)0;
     wfence();
 
@@ -394,21 +399,21 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
       band_width = x_drop = 0;
     }
 
-    const uint64_t cand0 = p.read_cand_off[idx];
+    const uint64_t cand0 = uload(&p.read_cand_off[idx]);
     Cand* cands = p.cands + cand0;
     uint32_t* order = p.order + 2 * cand0;  // two scratch lists of the read's hit count each
-    const uint64_t n_hits_cap = p.read_cand_off[idx + 1] - cand0;
+    const uint64_t n_hits_cap = uload(&p.read_cand_off[idx + 1]) - cand0;
     uint32_t n_acc = 0;
 
     PROF_MARK(c, PS_SETUP);
-    const uint64_t s0 = p.read_smem_off[idx];
-    uint32_t n_sm = p.read_smem_cnt[idx];
-    if (p.read_cand_off[idx + 1] > p.cand_cap) {  // candidate pool too small: the host grows it and reruns
+    const uint64_t s0 = uload(&p.read_smem_off[idx]);
+    uint32_t n_sm = uload(&p.read_smem_cnt[idx]);
+    if (cand0 + n_hits_cap > p.cand_cap) {  // candidate pool too small: the host grows it and reruns
       c.fault |= FAULT_OPS_POOL;
       n_sm = 0;
     }
     for (uint32_t si = 0; si < n_sm; si++) {
-      const Smem sm = p.smems[s0 + si];
+      const Smem sm = uload(&p.smems[s0 + si]);
       const int q = sm.qpos, len = sm.len;
       uint32_t rr = sm.hi;
       while (rr > sm.lo) {
@@ -416,11 +421,11 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
         uint32_t my_sa = 0;
         if ((uint32_t)lane < chunk) my_sa = ix.sa[rr - 1 - lane];
         for (uint32_t t = 0; t < chunk; t++) {
-          const long long hr = (long long)(uint32_t)__builtin_amdgcn_readlane((int)my_sa, bcast_first((int)t));
+          const int hr = __builtin_amdgcn_readlane((int)my_sa, bcast_first((int)t));
           // ================= align_seed_hit (src/aligner.rs:198-314) =================
           const int bw = band_width, xd = x_drop;
-          const RefInfo ref = idx_to_ref(ix, (uint64_t)hr);
-          const uint64_t qs = (uint64_t)hr, qe = (uint64_t)(hr + len);  // the seed on the concatenated text
+          const RefInfo ref = idx_to_ref(ix, (uint32_t)hr);
+          const uint32_t qs = (uint32_t)hr, qe = (uint32_t)(hr + len);  // the seed on the concatenated text
 
           // One loop runs the genome extension (target 0) and then one extension per
           // transcript yielded by exon_to_tx.find (:231-258), so that the extension
@@ -436,15 +441,15 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           int sp = 0;
           bool genome_done = false;
           for (;;) {
-            long long win0, lo_abs, hi_abs, t_r;
+            int win0, lo_abs, hi_abs, t_r;
             int t_q, t_len;
             uint8_t* buf;
             uint32_t tx_idx = 0;
             if (!genome_done) {
               // genome window (:212-215)
-              const long long rs = (long long)ref.start;
-              const long long seq_start = max((hr > (long long)(L + bw)) ? hr - (L + bw) : 0LL, rs);
-              const long long seq_end = min(hr + len + L + bw, (long long)ref.end - 1);
+              const int rs = (int)ref.start;
+              const int seq_start = max((hr > L + bw) ? hr - (L + bw) : 0, rs);
+              const int seq_end = min(hr + len + L + bw, (int)ref.end - 1);
               win0 = stage_window(c, ix.text, seq_start, seq_end);
               lo_abs = seq_start;
               hi_abs = seq_end;
@@ -459,8 +464,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               while (sp > 0 && !found) {
                 const int ni = bcast_first(c.stack[--sp]);  // uniform: the node comes through the scalar cache
                 wfence();
-                const TreeNode nd = ix.exon_tree[ni];
-                if (qs < nd.max) {
+                const TreeNode nd = uload(&ix.exon_tree[ni]);
+                if (qs < (uint32_t)nd.max) {
                   if (sp >= 60) {
                     c.fault |= FAULT_INTERNAL;
                     sp = 0;
@@ -470,12 +475,12 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
                     if (lane == 0) c.stack[sp] = nd.left;
                     sp++;
                   }
-                  if (qe > nd.start) {
+                  if (qe > (uint32_t)nd.start) {
                     if (nd.right >= 0) {
                       if (lane == 0) c.stack[sp] = nd.right;
                       sp++;
                     }
-                    if (qs < nd.end && nd.start < qe) {
+                    if (qs < (uint32_t)nd.end && (uint32_t)nd.start < qe) {
                       found = true;
                       tx_idx = nd.value;
                     }
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               }
               PROF_MARK(c, PS_TREE);
               if (!found) break;
-              const thm_tx tx = ix.txs[tx_idx];
+              const thm_tx tx = uload(&ix.txs[tx_idx]);
               // lift_mem_to_tx (src/txome.rs:82-103): first exon in transcript order that intersects
               int fe = -1;
               for (uint32_t e0 = 0; e0 < tx.n_exons && fe < 0; e0 += 64) {
@@ -493,7 +498,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
                 bool hit = false;
                 if (e < tx.n_exons) {
                   const thm_exon x = ix.exons[tx.exon_begin + e];
-                  hit = (qs >= x.start && qs < x.end) || (x.start >= qs && x.start < qe);
+                  const uint32_t x0 = (uint32_t)x.start, x1 = (uint32_t)x.end;
+                  hit = (qs >= x0 && qs < x1) || (x0 >= qs && x0 < qe);
                 }
                 const unsigned long long m = __ballot(hit);
                 if (m) fe = (int)e0 + __builtin_ctzll(m);
@@ -502,25 +508,25 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
                 c.fault |= FAULT_CONTRACT;
                 continue;
               }
-              const thm_exon x = ix.exons[tx.exon_begin + fe];
-              const long long exon_sum = (long long)ix.exon_txoff[tx.exon_begin + fe];
-              const long long xs = (long long)x.start, xe = (long long)x.end;
+              const thm_exon x = uload(&ix.exons[tx.exon_begin + fe]);
+              const int exon_sum = (int)uload(&ix.exon_txoff[tx.exon_begin + fe]);
+              const int xs = (int)x.start, xe = (int)x.end;
               t_r = ((hr > xs) ? hr - xs : 0) + exon_sum;
-              const long long start_offset = (xs > hr) ? xs - hr : 0;
-              const long long t_end = min(hr + len, xe) - xs + exon_sum;
-              t_q = q + (int)start_offset;
-              t_len = (int)(t_end - t_r);
-              const long long tlen = (long long)tx.seq_len;
+              const int start_offset = (xs > hr) ? xs - hr : 0;
+              const int t_end = min(hr + len, xe) - xs + exon_sum;
+              t_q = q + start_offset;
+              t_len = t_end - t_r;
+              const int tlen = (int)tx.seq_len;
               // window of the transcript around the lifted seed
-              const long long ws = (t_r > (long long)(L + bw)) ? t_r - (L + bw) : 0;
-              const long long we = min(tlen, t_r + t_len + L + bw + 1);
+              const int ws = (t_r > L + bw) ? t_r - (L + bw) : 0;
+              const int we = min(tlen, t_r + t_len + L + bw + 1);
               win0 = stage_window(c, ix.tx_seq + tx.seq_off, ws, we);
               // extend_seed_match (src/aligner.rs:410-426): ballots of the first mismatch
               {
                 int ext = 0;
                 for (bool done = false; !done;) {
                   const int tt = ext + lane;
-                  const long long rp = t_r + t_len + tt;
+                  const int rp = t_r + t_len + tt;
                   const int qp = t_q + t_len + tt;
                   const bool ok = (rp < tlen) && (qp < L) && (c.win[rp - win0] == c.rd[qp]);
                   const unsigned long long bad = __ballot(!ok);
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
                 ext = 0;
                 for (bool done = false; !done;) {
                   const int tt = ext + lane + 1;
-                  const long long rp = t_r - tt;
+                  const int rp = t_r - tt;
                   const int qp = t_q - tt;
                   const bool ok = (rp >= 0) && (qp >= 0) && (c.win[rp - win0] == c.rd[qp]);
                   const unsigned long long bad = __ballot(!ok);
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           // ---- exonic vs unspliced (:263-313) ----
           int aln_type;
           uint32_t type_idx = THM_NO_IDX;
-          long long cy0, cy1;  // concatenated coordinates of the genome alignment
+          int cy0, cy1;  // concatenated coordinates of the genome alignment
           const uint8_t* g_path;
           int g_n, g_ny = 0;
           int sc, xs_, xe_;
@@ -609,10 +615,10 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           if (sc < p.opts.min_aln_score || sc < min_aln_score || sc < max_aln_score - range) accept = false;
           if (accept) {
             if (exonic) {
-              g_ny = lift_markers(c, ix, ix.txs[best_tx], best_buf, best.nops, best.xend < L, best.ystart, best.yend, cy0, cy1);
+              g_ny = lift_markers(c, ix, uload(&ix.txs[best_tx]), best_buf, best.nops, best.xend < L, best.ystart, best.yend, cy0, cy1);
             } else {
               // first interval gene_intervals.find yields (:283-288, :306); only reached in intron mode
-              const uint64_t gs = (uint64_t)cy0, ge_ = (uint64_t)cy1;
+              const uint32_t gs = (uint32_t)cy0, ge_ = (uint32_t)cy1;
               int gsp = 0;
               if (ix.gene_root >= 0) {
                 if (lane == 0) c.stack[0] = ix.gene_root;
@@ -622,18 +628,18 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               while (gsp > 0) {
                 const int ni = bcast_first(c.stack[--gsp]);
                 wfence();
-                const TreeNode nd = ix.gene_tree[ni];
-                if (gs < nd.max) {
+                const TreeNode nd = uload(&ix.gene_tree[ni]);
+                if (gs < (uint32_t)nd.max) {
                   if (nd.left >= 0 && gsp < 60) {
                     if (lane == 0) c.stack[gsp] = nd.left;
                     gsp++;
                   }
-                  if (ge_ > nd.start) {
+                  if (ge_ > (uint32_t)nd.start) {
                     if (nd.right >= 0 && gsp < 60) {
                       if (lane == 0) c.stack[gsp] = nd.right;
                       gsp++;
                     }
-                    if (gs < nd.end && nd.start < ge_) {
+                    if (gs < (uint32_t)nd.end && (uint32_t)nd.start < ge_) {
                       aln_type = THM_ALN_INTRONIC;
                       type_idx = nd.value;
                       break;
@@ -645,16 +651,16 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               PROF_MARK(c, PS_TREE);
             }
             // concat_to_chr_aln (:429-449)
-            const RefInfo cref = idx_to_ref(ix, (uint64_t)cy0);
-            uint64_t ch0, ch1;
+            const RefInfo cref = idx_to_ref(ix, (uint32_t)cy0);
+            uint32_t ch0, ch1;
             bool rev;
             if (cref.strand) {
-              ch0 = (uint64_t)cy0 - cref.start;
-              ch1 = (uint64_t)cy1 - cref.start;
+              ch0 = (uint32_t)cy0 - cref.start;
+              ch1 = (uint32_t)cy1 - cref.start;
               rev = false;
             } else {
-              ch0 = cref.len - ((uint64_t)cy1 - cref.start);
-              ch1 = cref.len - ((uint64_t)cy0 - cref.start);
+              ch0 = cref.len - ((uint32_t)cy1 - cref.start);
+              ch1 = cref.len - ((uint32_t)cy0 - cref.start);
               rev = true;
             }
             int nb = 0, tnb = 0;
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               if (exonic) {
                 cd.tx_ystart = (uint64_t)best.ystart;
                 cd.tx_yend = (uint64_t)best.yend;
-                cd.tx_ylen = ix.txs[best_tx].seq_len;
+                cd.tx_ylen = uload(&ix.txs[best_tx].seq_len);
                 cd.tx_ops_off = toff2;
                 cd.tx_ops_len = (uint32_t)tnb;
                 cd.tx_score = best.score;
@@ -717,6 +723,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
     uint32_t* lb = order + n_hits_cap;  // list B
     uint32_t m = 0;
     // retain(score >= max - range), keeps order
+    #pragma unroll 1
     for (uint32_t t0 = 0; t0 < n_acc; t0 += 64) {
       const uint32_t t = t0 + lane;
       const bool keep = (t < n_acc) && (cands[t].score >= max_aln_score - range);
@@ -730,6 +737,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
       nres = 1;
     } else if (m > 1) {
       // stable sort by (ref_name, strand, ystart) (:322-327): rank sort la -> lb
+      #pragma unroll 1
       for (uint32_t t0 = 0; t0 < m; t0 += 64) {
         const uint32_t t = t0 + lane;
         if (t < m) {
@@ -779,6 +787,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
       }
       __threadfence_block();
       // stable sort by -score (:183): rank sort la -> lb, then copy back
+      #pragma unroll 1
       for (uint32_t t0 = 0; t0 < nres; t0 += 64) {
         const uint32_t t = t0 + lane;
         if (t < nres) {
@@ -792,11 +801,13 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
         }
       }
       __threadfence_block();
+      #pragma unroll 1
       for (uint32_t t = lane; t < nres; t += 64) la[t] = lb[t];
       __threadfence_block();
     }
     // per-read totals
     unsigned long long opb = 0;
+    #pragma unroll 1
     for (uint32_t t = lane; t < nres; t += 64) {
       const Cand a = cands[la[t]];
       opb += a.ops_len + a.tx_ops_len;
@@ -865,9 +876,11 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
   const uint64_t a0 = p.read_aln_off[r];
   for (uint32_t t = 0; t < n; t++) {
     const Cand cd = cands[la[t]];
+    #pragma unroll 1
     for (uint32_t b = lane; b < cd.ops_len; b += 64) p.ops[o + b] = p.cand_ops[cd.ops_off + b];
     const uint64_t go = o;
     o += cd.ops_len;
+    #pragma unroll 1
     for (uint32_t b = lane; b < cd.tx_ops_len; b += 64) p.ops[o + b] = p.cand_ops[cd.tx_ops_off + b];
     const uint64_t to = o;
     o += cd.tx_ops_len;

@@ -151,7 +151,7 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
 __global__ __launch_bounds__(256) void seed_kernel(SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
   const uint32_t lcap = (p.max_read_len + 31u) & ~15u;  // >= L + 16, multiple of 16
   const uint32_t per_wave = lcap * 26;
   uint8_t* base = smem + (size_t)wave * per_wave;

@@ -14,7 +14,7 @@ template <int CPL>
 __global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
   const uint32_t tr_bytes = (p.y_cap + 1) * CPL * 16;
   const uint32_t ops_cap = p.x_cap + p.y_cap + 16;
   const uint32_t per_wave = p.x_cap + p.y_cap + tr_bytes + ops_cap;
@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
     const int xd = p.xd[idx];
     // only the first xlen+bw+1 columns are reachable
     const int ylen = min(ylen_full, xlen + bw + 1);
+    #pragma unroll 1
     for (int t = lane; t < xlen; t += 64) xs[t] = p.xb[x0 + t];
+    #pragma unroll 1
     for (int t = lane; t < ylen; t += 64) ys[t] = p.yb[y0 + t];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
     }
     uint8_t* out = p.ops + p.ops_off[idx];
     const uint8_t* src = opsb + ops_cap - nops;
+    #pragma unroll 1
     for (int t = lane; t < nops; t += 64) out[t] = src[t];
     uint32_t total = (uint32_t)nops;
     if (r.xend < xlen) {  // reference :178-180 Xclip(len - i), last after the reverse

@@ -67,6 +67,24 @@ __device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlan
 __device__ __forceinline__ int wave_min(int v) { return -wave_max(-v); }
 __device__ __forceinline__ int bcast_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Load through the constant address space: with a wave-uniform address this
+// becomes an s_load (scalar cache, result in SGPRs, no EXEC games in the control
+// flow that depends on it).  Only for data no kernel instance writes while it
+// runs (the index, the read batch, the outputs of earlier kernels).
+template <class T>
+__device__ __forceinline__ T uload(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) T* cptr;
+  // readfirstlane pins the address as wave-uniform for the compiler as well
+  const uintptr_t a = (uintptr_t)p;
+  const uintptr_t u = ((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                      (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  return *(cptr)u;
+#else
+  return *p;
+#endif
+}
+
 struct SwgResult {
   int score, xend, yend;
   unsigned cells, cols;  // cells / columns actually computed (the early exit below makes this <= the reference's count)
@@ -321,6 +339,7 @@ __device__ int swg_traceback_wave(const unsigned long long* trace, int i, int j,
   while (i > 0 || j > 0) {
     if (j == 0) {  // column 0 is all Ins (reference :65,:70): i more insertions
       if (n + i > max_ops) return -1;
+      #pragma unroll 1
       for (int s = lane; s < i; s += 64) ops[(n + s) * stride] = (uint8_t)OPK_INS;
       n += i;
       break;
