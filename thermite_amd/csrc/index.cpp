@@ -237,7 +237,7 @@ int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_re
   thm_index* ix = new thm_index();
   ix->n = n;
   ix->text.assign(text, text + n);
-  ix->text.resize(n + 16, (uint8_t)'$');  // padding so 16-byte loads near the end stay in bounds
+  ix->text.resize(n + 128, (uint8_t)'$');  // padding: batched 64-byte compares / 16-byte window loads may run past the end
   ix->refs.assign(refs, refs + n_refs);
   ix->name_rank.resize(n_refs);
   for (uint32_t i = 0; i < n_refs; i++) ix->name_rank[i] = name_rank ? name_rank[refs[i].name_id] : refs[i].name_id;

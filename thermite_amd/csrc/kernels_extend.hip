@@ -936,17 +936,21 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
-  // register budget: MINW waves per SIMD (default 4; tuning knob THM_EXT_MINW = 2 | 3 | 4)
+  // register budget: MINW waves per SIMD (default 4; tuning knob THM_EXT_MINW = 2..6 | 8)
   static const int minw = [] {
     const char* e = getenv("THM_EXT_MINW");
     const int v = e ? atoi(e) : 4;
-    return (v == 3 || v == 4) ? v : 2;
+    return (v >= 2 && v <= 8) ? v : 4;
   }();
 #define THM_EXT_CASE(C)                                  \
   case C:                                                \
     if (minw == 4) return go(dev::extend_kernel<C, 4>);  \
     if (minw == 3) return go(dev::extend_kernel<C, 3>);  \
-    return go(dev::extend_kernel<C, 2>);
+    if (minw == 2) return go(dev::extend_kernel<C, 2>);  \
+    if (C <= 2 && minw == 5) return go(dev::extend_kernel<(C <= 2 ? C : 1), 5>);  \
+    if (C <= 2 && minw == 6) return go(dev::extend_kernel<(C <= 2 ? C : 1), 6>);  \
+    if (C <= 2 && minw == 8) return go(dev::extend_kernel<(C <= 2 ? C : 1), 8>);  \
+    return go(dev::extend_kernel<C, 4>);
   switch (cpl) {
     THM_EXT_CASE(1)
     THM_EXT_CASE(2)

@@ -45,24 +45,51 @@ __device__ __forceinline__ uint64_t load8_lds(const uint8_t* base16, int off) {
   return sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
 }
 
-// LCP of the query tail rd[qoff..L) with the text at tp, 8 bytes per step; *less
-// tells whether the text suffix sorts before the query (a suffix that has the whole
-// query tail as a prefix is >= it).  At most `cap` characters are compared.
+// LCP of the query tail rd[qoff..L) with the text at tp; *less tells whether the
+// text suffix sorts before the query (a suffix that has the whole query tail as a
+// prefix is >= it).  At most `cap` characters are compared.  The text bytes are
+// fetched 64 at a time with all eight loads in flight together (one memory round
+// trip per 64 characters instead of one per 8); PROBE first looks at 8 bytes only,
+// which settles most comparisons of a binary search.  The text carries 128 bytes
+// of padding, so the speculative tail of a batch stays inside the allocation.
+template <bool PROBE>
 __device__ __forceinline__ int lcp_cmp(const uint8_t* tp, const uint8_t* rd, int qoff, int cap, bool* less) {
-  int o = 0;
   *less = false;
-  while (o < cap) {
-    const uint64_t tw = load8_global(tp + o), qw = load8_lds(rd, qoff + o);
+  int o = 0;
+  if (PROBE && cap > 0) {
+    const uint64_t tw = load8_global(tp), qw = load8_lds(rd, qoff);
     const uint64_t x = tw ^ qw;
     if (x) {
       const int idx = __builtin_ctzll(x) >> 3;
-      if (o + idx < cap) {
+      if (idx < cap) {
         *less = ((tw >> (8 * idx)) & 0xff) < ((qw >> (8 * idx)) & 0xff);
-        return o + idx;
+        return idx;
       }
       return cap;
     }
-    o += 8;
+    o = 8;
+  }
+  while (o < cap) {
+    uint64_t tw[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) tw[u] = load8_global(tp + o + 8 * u);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int oo = o + 8 * u;
+      if (oo < cap) {
+        const uint64_t qw = load8_lds(rd, qoff + oo);
+        const uint64_t x = tw[u] ^ qw;
+        if (x) {
+          const int idx = __builtin_ctzll(x) >> 3;
+          if (oo + idx < cap) {
+            *less = ((tw[u] >> (8 * idx)) & 0xff) < ((qw >> (8 * idx)) & 0xff);
+            return oo + idx;
+          }
+          return cap;
+        }
+      }
+    }
+    o += 64;
   }
   return cap;
 }
@@ -98,20 +125,20 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
     const int cap = L - (pos + d);
     bool less;
     if (hi - lo == 1) {
-      d += lcp_cmp(ix.text + ix.sa[lo] + d, rd, pos + d, cap, &less);
+      d += lcp_cmp<false>(ix.text + ix.sa[lo] + d, rd, pos + d, cap, &less);
     } else if (rd[pos + d] != 0) {  // a byte outside ACGTN matches nothing: the interval stays at depth d
       uint32_t a = lo, b = hi;
       while (a < b) {
         const uint32_t m = a + ((b - a) >> 1);
-        (void)lcp_cmp(ix.text + ix.sa[m] + d, rd, pos + d, cap, &less);
+        (void)lcp_cmp<true>(ix.text + ix.sa[m] + d, rd, pos + d, cap, &less);
         if (less)
           a = m + 1;
         else
           b = m;
       }
       int l1 = -1, l2 = -1;
-      if (a > lo) l1 = lcp_cmp(ix.text + ix.sa[a - 1] + d, rd, pos + d, cap, &less);
-      if (a < hi) l2 = lcp_cmp(ix.text + ix.sa[a] + d, rd, pos + d, cap, &less);
+      if (a > lo) l1 = lcp_cmp<true>(ix.text + ix.sa[a - 1] + d, rd, pos + d, cap, &less);
+      if (a < hi) l2 = lcp_cmp<true>(ix.text + ix.sa[a] + d, rd, pos + d, cap, &less);
       const int ms = max(l1, l2);
       if (ms > 0) {
         uint32_t nlo = a, nhi = a;
@@ -119,7 +146,7 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
           uint32_t x = lo, y = a - 1;
           while (x < y) {
             const uint32_t m = x + ((y - x) >> 1);
-            if (lcp_cmp(ix.text + ix.sa[m] + d, rd, pos + d, ms, &less) >= ms)
+            if (lcp_cmp<true>(ix.text + ix.sa[m] + d, rd, pos + d, ms, &less) >= ms)
               y = m;
             else
               x = m + 1;
@@ -130,7 +157,7 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
           uint32_t x = a + 1, y = hi;
           while (x < y) {
             const uint32_t m = x + ((y - x) >> 1);
-            if (lcp_cmp(ix.text + ix.sa[m] + d, rd, pos + d, ms, &less) >= ms)
+            if (lcp_cmp<true>(ix.text + ix.sa[m] + d, rd, pos + d, ms, &less) >= ms)
               x = m + 1;
             else
               y = m;
