@@ -72,7 +72,8 @@ __device__ RefInfo idx_to_ref(const DeviceIndex& ix, uint32_t idx) {
 // wave-private LDS carve-up
 struct Wctx {
   uint8_t* rd;   // sanitised read, zero padded
-  uint8_t* win;  // reference / transcript window (16-byte aligned copy)
+  uint8_t* win;   // window the extension reads (genome or transcript; 16-byte aligned copy)
+  uint8_t* wing;  // the hit's genome window, kept while its transcripts are tried
   unsigned long long* trace;
   uint8_t* pa;  // three path buffers (op kinds 0..3), rotated by pointer swap
   uint8_t* pb;
@@ -111,6 +112,15 @@ struct Path {
   int ystart, yend;  // in the coordinates r / lo_abs were given in
 };
 
+// what extend_lr did for the hit's genome window, for reuse by its transcripts
+struct LrMemo {
+  SwgResult R, Lt;
+  int nr, nl;
+  int yr, yl;    // columns that were available to the right / left extension
+  int yoff_r;    // offset in the window buffer of y[0] of the right extension
+  int yoff_l;    // offset of y[0] of the left extension (which walks backwards)
+};
+
 // One SwgExtend::extend + trace.  The band slots that can ever hold a cell number
 // min(2*bw+1, |x|+1): when that fits 64 the one-cell-per-lane code is exact even
 // inside a kernel compiled for a wider band (slots >= |x|+1 are never valid), and
@@ -138,7 +148,8 @@ __device__ __forceinline__ int swg_and_trace(Wctx& c, const uint8_t* xs, int dx,
 // extend_left_right, reference src/aligner.rs:352-407.  `win` holds ref_seq bytes
 // from absolute coordinate win0; ref_seq itself spans [lo_abs, hi_abs).
 template <int CPL>
-__device__ Path extend_lr(Wctx& c, int win0, int lo_abs, int hi_abs, int r, int q, int len, int bw, int xd, uint8_t* buf) {
+__device__ Path extend_lr(Wctx& c, const uint8_t* win, int win0, int lo_abs, int hi_abs, int r, int q, int len, int bw, int xd,
+                          uint8_t* buf, LrMemo& memo) {
   const int L = c.L;
   Path p;
   PROF_MARK(c, PS_OTHER);
@@ -147,14 +158,14 @@ __device__ Path extend_lr(Wctx& c, int win0, int lo_abs, int hi_abs, int r, int 
   const int yr_avail = hi_abs - (r + len);
   const int yr = min(yr_avail, xr + bw + 1);
   SwgResult R, Lt;
-  int nr = swg_and_trace<CPL>(c, c.rd + q + len, 1, xr, c.win + (r + len - win0), 1, yr, bw, xd, buf + c.opcap - 1, -1,
+  int nr = swg_and_trace<CPL>(c, c.rd + q + len, 1, xr, win + (r + len - win0), 1, yr, bw, xd, buf + c.opcap - 1, -1,
                               c.opcap, R);
   // left: both reversed, y = ref_seq[r.saturating_sub(L+bw)..r]   (:364-375)
   const int xl = q;
   const int rel = r - lo_abs;
   const int y0 = lo_abs + (rel > L + bw ? rel - (L + bw) : 0);
   const int yl = min(r - y0, xl + bw + 1);
-  int nl = swg_and_trace<CPL>(c, c.rd + q - 1, -1, xl, c.win + (r - 1 - win0), -1, yl, bw, xd, buf, 1,
+  int nl = swg_and_trace<CPL>(c, c.rd + q - 1, -1, xl, win + (r - 1 - win0), -1, yl, bw, xd, buf, 1,
                               c.opcap - max(nr, 0), Lt);
   c.cells += R.cells + Lt.cells;
   c.cols += R.cols + Lt.cols;
@@ -178,6 +189,14 @@ __device__ Path extend_lr(Wctx& c, int win0, int lo_abs, int hi_abs, int r, int 
     wfence();
   }
   PROF_MARK(c, PS_TRACEBACK);
+  memo.R = R;
+  memo.Lt = Lt;
+  memo.nr = nr;
+  memo.nl = nl;
+  memo.yr = yr;
+  memo.yl = yl;
+  memo.yoff_r = r + len - win0;
+  memo.yoff_l = r - 1 - win0;
   p.nops = nl + len + nr;
   p.score = Lt.score + len * MATCH_SCORE + R.score;
   p.ystart = r - Lt.yend;
@@ -190,7 +209,7 @@ __device__ Path extend_lr(Wctx& c, int win0, int lo_abs, int hi_abs, int r, int 
 // Stage [a, b) of a global byte array into c.win with 16-byte loads.  Returns the
 // coordinate that c.win[0] corresponds to (a rounded down to the 16-byte grid of
 // the source address; the arrays carry 16 bytes of padding at both ends of use).
-__device__ int stage_window(Wctx& c, const uint8_t* src, int a, int b) {
+__device__ int stage_window(Wctx& c, uint8_t* dst, const uint8_t* src, int a, int b) {
   const unsigned mis = (unsigned)((uintptr_t)(src + a) & 15u);
   const int n = (b - a) + (int)mis;
   if (n > c.wcap) {
@@ -198,7 +217,7 @@ __device__ int stage_window(Wctx& c, const uint8_t* src, int a, int b) {
     return a;
   }
   const uint4* g = (const uint4*)(src + a - mis);
-  uint4* w = (uint4*)c.win;
+  uint4* w = (uint4*)dst;
   for (int t = lane_id(); t * 16 < n; t += 64) w[t] = g[t];
   c.winbytes += (unsigned)(b - a);
   wfence();
@@ -348,12 +367,13 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   const uint32_t ycols = p.max_read_len + p.max_bw + 2u;
   const uint32_t trb = (ycols + 1u) * CPL * 16u;
   const uint32_t opcap = (2u * p.max_read_len + 2u * p.max_bw + 31u) & ~15u;
-  const uint32_t per_wave = lcap + wcap + trb + 3u * opcap + 8u * MAX_YCLIPS + 256u;
+  const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * MAX_YCLIPS + 256u;
   uint8_t* base = smem + (size_t)wave * per_wave;
   Wctx c;
   c.rd = base;
   c.win = c.rd + lcap;
-  c.trace = (unsigned long long*)(c.win + wcap);
+  c.wing = c.win + wcap;
+  c.trace = (unsigned long long*)(c.wing + wcap);
   c.pa = (uint8_t*)c.trace + trb;
   c.pb = c.pa + opcap;
   c.pc = c.pb + opcap;
@@ -440,6 +460,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           uint8_t* best_buf = c.pc;
           int sp = 0;
           bool genome_done = false;
+          LrMemo gmemo, tmemo;
           for (;;) {
             int win0, lo_abs, hi_abs, t_r;
             int t_q, t_len;
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               const int rs = (int)ref.start;
               const int seq_start = max((hr > L + bw) ? hr - (L + bw) : 0, rs);
               const int seq_end = min(hr + len + L + bw, (int)ref.end - 1);
-              win0 = stage_window(c, ix.text, seq_start, seq_end);
+              win0 = stage_window(c, c.wing, ix.text, seq_start, seq_end);
               lo_abs = seq_start;
               hi_abs = seq_end;
               t_r = hr;
@@ -520,7 +541,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               // window of the transcript around the lifted seed
               const int ws = (t_r > L + bw) ? t_r - (L + bw) : 0;
               const int we = min(tlen, t_r + t_len + L + bw + 1);
-              win0 = stage_window(c, ix.tx_seq + tx.seq_off, ws, we);
+              win0 = stage_window(c, c.win, ix.tx_seq + tx.seq_off, ws, we);
               // extend_seed_match (src/aligner.rs:410-426): ballots of the first mismatch
               {
                 int ext = 0;
@@ -561,7 +582,57 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               buf = cur_buf;
               PROF_MARK(c, PS_TXPREP);
             }
-            const Path pth = extend_lr<CPL>(c, win0, lo_abs, hi_abs, t_r, t_q, t_len, bw, xd, buf);
+            Path pth;
+            bool reused = false;
+            if (genome_done && t_q == q && t_len == len) {
+              // Same seed on the read: if the transcript window agrees with the genome
+              // window on every column the genome extensions looked at (the hit sits
+              // inside one exon and the alignment does not reach its ends), the two
+              // SwgExtend::extend calls would return what they returned for the genome.
+              const int xr = L - (t_q + t_len);
+              const int yr = min(hi_abs - (t_r + t_len), xr + bw + 1);
+              const int rel = t_r - lo_abs;
+              const int y0 = lo_abs + (rel > L + bw ? rel - (L + bw) : 0);
+              const int yl = min(t_r - y0, t_q + bw + 1);
+              const SwgResult& R = gmemo.R;
+              const SwgResult& Lt = gmemo.Lt;
+              bool ok = (R.broke ? yr >= R.jmax : yr == gmemo.yr) && (Lt.broke ? yl >= Lt.jmax : yl == gmemo.yl);
+              if (ok) {
+                const uint8_t* tr_ = c.win + (t_r + t_len - win0);
+                const uint8_t* gr_ = c.wing + gmemo.yoff_r;
+                const uint8_t* tl_ = c.win + (t_r - 1 - win0);
+                const uint8_t* gl_ = c.wing + gmemo.yoff_l;
+                bool differ = false;
+#pragma unroll 1
+                for (int j0 = 0; j0 < R.jmax; j0 += 64) {
+                  const int j = j0 + lane;
+                  differ = differ || (j < R.jmax && tr_[j] != gr_[j]);
+                }
+#pragma unroll 1
+                for (int j0 = 0; j0 < Lt.jmax; j0 += 64) {
+                  const int j = j0 + lane;
+                  differ = differ || (j < Lt.jmax && tl_[-j] != gl_[-j]);
+                }
+                ok = __ballot(differ) == 0ull;
+              }
+              if (ok) {
+                reused = true;
+                pth.score = gx.score;
+                pth.nops = gx.nops;
+                pth.xstart = gx.xstart;
+                pth.xend = gx.xend;
+                pth.ystart = t_r - Lt.yend;
+                pth.yend = t_r + t_len + R.yend;
+#pragma unroll 1
+                for (int t2 = lane; t2 < gx.nops; t2 += 64) buf[t2] = c.pa[t2];
+                wfence();
+                c.calls += 2;  // two extend() calls in the reference's terms
+                PROF_MARK(c, PS_TXPREP);
+              }
+            }
+            if (!reused)
+              pth = extend_lr<CPL>(c, genome_done ? c.win : c.wing, win0, lo_abs, hi_abs, t_r, t_q, t_len, bw, xd, buf,
+                                   genome_done ? tmemo : gmemo);
             if (!genome_done) {
               gx = pth;
               genome_done = true;
@@ -922,7 +993,7 @@ size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
   const uint32_t ycols = max_read_len + max_bw + 2u;
   const uint32_t trb = (ycols + 1u) * cpl * 16u;
   const uint32_t opcap = (2u * max_read_len + 2u * max_bw + 31u) & ~15u;
-  const uint32_t per_wave = lcap + wcap + trb + 3u * opcap + 8u * dev::MAX_YCLIPS + 256u;
+  const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * dev::MAX_YCLIPS + 256u;
   return 4 * (size_t)per_wave;
 }
 

@@ -88,6 +88,13 @@ __device__ __forceinline__ T uload(const T* p) {
 struct SwgResult {
   int score, xend, yend;
   unsigned cells, cols;  // cells / columns actually computed (the early exit below makes this <= the reference's count)
+  // What the result depends on: y[0..jmax) and, when `broke` is false (the loop ran
+  // out of columns), on ylen itself.  A second problem with the same x, band and
+  // X-drop whose y agrees on [0, jmax) -- and has ylen >= jmax if broke, the same
+  // ylen otherwise -- has the same result (used to skip the transcript extension
+  // when it would repeat the genome extension).
+  int jmax;
+  bool broke;
 };
 
 // ---- fused DPP steps for the per-column scan (the hot loop) ----
@@ -146,6 +153,8 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
   res.yend = 0;
   res.cells = 0;
   res.cols = 0;
+  res.jmax = 0;
+  res.broke = (xlen == 0);  // an empty x gives the empty result for any y; an empty y is "ran out of columns"
   if (xlen == 0 || ylen == 0) return res;  // reference :39-55
 
   const int lane = lane_id();
@@ -224,8 +233,10 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
       if (m_imp) run_max += MATCH_SCORE;
       // reference :110: with x_drop >= band_width the X-drop test cannot fire in
       // phase 1; the early exit is ours (see above)
+      res.jmax = j;
       if (!m_alive) {  // (an improving lane is alive by construction)
         finished = true;
+        res.broke = true;
         break;
       }
     }
@@ -236,7 +247,11 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
     for (int j = bw + 1; j <= ylen; j++) {
       const int top = j - bw;
       res.cols += 1;
-      if (top > xlen) break;  // empty row range: band_max = MIN -> X-drop (reference :117-153)
+      if (top > xlen) {  // empty row range: band_max = MIN -> X-drop (reference :117-153)
+        res.broke = true;
+        break;
+      }
+      res.jmax = j;
       const int rows_end = min(top + w, xlen + 1);  // exclusive row bound
       const int yc = (int)ys[(j - 1) * dy];
       int d[CPL], Cn[CPL], key[CPL], xc[CPL], base[CPL];
@@ -293,8 +308,10 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         run_max += MATCH_SCORE;
         continue;  // the improving cell equals the new maximum: neither X-drop nor the early exit can apply
       }
-      if (!m_x) break;      // reference :151  band_max < max_score - x_drop
-      if (!m_alive) break;  // early exit: the result can no longer change
+      if (!m_x || !m_alive) {  // reference :151 (band_max < max_score - x_drop), or our early exit
+        res.broke = true;
+        break;
+      }
     }
   }
 
