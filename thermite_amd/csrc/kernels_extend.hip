@@ -84,6 +84,8 @@ struct Wctx {
   int L, opcap, wcap;
   unsigned cells, cols, calls, winbytes;
   int fault;
+  unsigned long long pool_off;  // wave-private slice of the global op pool (bump allocated)
+  unsigned pool_left;
 #ifdef THM_PROF
   unsigned long long prof_last;
   unsigned long long prof_acc[10];
@@ -321,13 +323,23 @@ __device__ unsigned long long emit_alignment(Wctx& c, const ExtendParams& p, con
   const int lead5 = lead > 0 ? 5 : 0, trail5 = trail > 0 ? 5 : 0;
   const int total = lead5 + n + 5 * n_y + trail5;
   n_bytes = total;
-  unsigned long long off = 0;
-  if (lane == 0) off = atomicAdd(p.ops_cursor, (unsigned long long)total);
-  off = bcast64(off);
-  if (off + (unsigned long long)total > p.cand_ops_cap) {
-    c.fault |= FAULT_OPS_POOL;
-    return 0;
+  // the op pool is handed out to waves in 4 KiB slices (one atomic per slice, not per alignment)
+  if ((unsigned)total > c.pool_left) {
+    const unsigned grab = max(4096u, (unsigned)total);
+    unsigned long long g = 0;
+    if (lane == 0) g = atomicAdd(p.ops_cursor, (unsigned long long)grab);
+    g = bcast64(g);
+    if (g + grab > p.cand_ops_cap) {
+      c.fault |= FAULT_OPS_POOL;
+      c.pool_left = 0;
+      return 0;
+    }
+    c.pool_off = g;
+    c.pool_left = grab;
   }
+  const unsigned long long off = c.pool_off;
+  c.pool_off += (unsigned)total;
+  c.pool_left -= (unsigned)total;
   uint8_t* o = p.cand_ops + off;
   auto put5 = [&](int pos, uint8_t kind, uint32_t v) {
     o[pos] = kind;
@@ -384,6 +396,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   c.wcap = (int)wcap;
   c.cells = c.cols = c.calls = c.winbytes = 0;
   c.fault = 0;
+  c.pool_off = 0;
+  c.pool_left = 0;
 #ifdef THM_PROF
   for (int t = 0; t < 10; t++) c.prof_acc[t] = 0;
   c.prof_last = __builtin_amdgcn_s_memtime();
@@ -393,11 +407,18 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_type[3] = {0, 0, 0}, k_reads = 0, k_opb = 0;
   unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
 
+  constexpr unsigned QCHUNK = 4;  // reads taken from the work queue per atomic
+  unsigned q_next = 0, q_end = 0;
   for (;;) {
-    unsigned idx = 0;
-    if (lane == 0) idx = atomicAdd(p.queue, 1u);
-    idx = (unsigned)bcast_first((int)idx);
-    if (idx >= p.reads.n_reads) break;
+    if (q_next == q_end) {
+      unsigned g = 0;
+      if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
+      g = (unsigned)bcast_first((int)g);
+      if (g >= p.reads.n_reads) break;
+      q_next = g;
+      q_end = min(g + QCHUNK, (unsigned)p.reads.n_reads);
+    }
+    const unsigned idx = q_next++;
     const uint64_t r0 = uload(&p.reads.offsets[idx]);
     const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
     c.L = L;
@@ -424,6 +445,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
     uint32_t* order = p.order + 2 * cand0;  // two scratch lists of the read's hit count each
     const uint64_t n_hits_cap = uload(&p.read_cand_off[idx + 1]) - cand0;
     uint32_t n_acc = 0;
+    unsigned acc_bytes = 0;  // op bytes and type of the most recent accepted candidate
+    int acc_type = 0;
 
     PROF_MARK(c, PS_SETUP);
     const uint64_t s0 = uload(&p.read_smem_off[idx]);
@@ -775,6 +798,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               cands[n_acc] = cd;
             }
             n_acc++;
+            acc_bytes = (unsigned)(nb + tnb);
+            acc_type = aln_type;
             PROF_MARK(c, PS_EMIT);
             // narrow the band (:162-172)
             const int lim = max(L + range - sc, 0);
@@ -786,9 +811,21 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
         rr -= chunk;
       }
     }
-    __threadfence_block();
     PROF_MARK(c, PS_OTHER);
-
+    uint32_t nres = 0;
+    unsigned long long opb = 0;
+    if (n_acc == 1) {
+      // the common case: one candidate, which by construction passes retain() (its score is the maximum)
+      nres = 1;
+      if (lane == 0) order[0] = 0;
+      opb = acc_bytes;
+      if (lane == 0) {
+        k_type[0] += (acc_type == THM_ALN_EXONIC);
+        k_type[1] += (acc_type == THM_ALN_INTRONIC);
+        k_type[2] += (acc_type == THM_ALN_INTERGENIC);
+      }
+    } else if (n_acc > 1) {
+      __threadfence_block();
     // ============ retain / filter_overlapping / sort / primary (:177-187) ============
     uint32_t* la = order;               // list A
     uint32_t* lb = order + n_hits_cap;  // list B
@@ -803,7 +840,6 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
       m += (uint32_t)__popcll(mk);
     }
     __threadfence_block();
-    uint32_t nres = 0;
     if (m == 1) {
       nres = 1;
     } else if (m > 1) {
@@ -876,17 +912,17 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
       for (uint32_t t = lane; t < nres; t += 64) la[t] = lb[t];
       __threadfence_block();
     }
-    // per-read totals
-    unsigned long long opb = 0;
-    #pragma unroll 1
-    for (uint32_t t = lane; t < nres; t += 64) {
-      const Cand a = cands[la[t]];
-      opb += a.ops_len + a.tx_ops_len;
-      k_type[0] += (a.aln_type == THM_ALN_EXONIC);
-      k_type[1] += (a.aln_type == THM_ALN_INTRONIC);
-      k_type[2] += (a.aln_type == THM_ALN_INTERGENIC);
+      // per-read totals
+      #pragma unroll 1
+      for (uint32_t t = lane; t < nres; t += 64) {
+        const Cand a = cands[la[t]];
+        opb += a.ops_len + a.tx_ops_len;
+        k_type[0] += (a.aln_type == THM_ALN_EXONIC);
+        k_type[1] += (a.aln_type == THM_ALN_INTRONIC);
+        k_type[2] += (a.aln_type == THM_ALN_INTERGENIC);
+      }
+      for (int o = 32; o > 0; o >>= 1) opb += __shfl_xor(opb, o);
     }
-    for (int o = 32; o > 0; o >>= 1) opb += __shfl_xor(opb, o);
     if (lane == 0) {
       p.read_n_alns[idx] = nres;
       p.read_op_bytes[idx] = opb;
