@@ -67,12 +67,12 @@ struct thm_aligner {
   DBuf b0, b1, b2, b3, b4, b5, b6, b7, b8;       // operator-level scratch
 
   // ---- read-level pipeline ----
-  DBuf r_bases, r_offsets;
+  DBuf r_bases, r_offsets, r_san;  // raw reads, offsets, upper-cased + sanitised copy (made by every run)
   uint64_t n_reads = 0, n_bases = 0;
   uint32_t max_read_len = 0;
   bool uploaded = false;
   // seeds
-  DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp;
+  DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp, s_ms_end, s_ms_lo, s_ms_hi;
   uint64_t smem_cap = 0;
   // extension
   DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off;

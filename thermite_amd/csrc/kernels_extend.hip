@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
     const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
     c.L = L;
     #pragma unroll 1
-    for (int t = lane; t < (int)lcap; t += 64) c.rd[t] = (t < L) ? sanitize_base_e(p.reads.bases[r0 + t]) : (uint8_t)0;
+    for (int t = lane; t < (int)lcap; t += 64) c.rd[t] = (t < L) ? p.reads.bases[r0 + t] : (uint8_t)0;  // already upper-cased and sanitised
     wfence();
 
     // thresholds, reference src/aligner.rs:130-138 (binary32 product, truncation toward zero)

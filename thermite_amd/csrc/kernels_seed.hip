@@ -4,7 +4,9 @@
 // wavefront.
 //
 // The reference walks an FMD index (bio 0.37.1, ~2L dependent Occ lookups per
-// read).  Here every read position is searched independently by one lane:
+// read).  Here every read position is searched independently by one thread
+// (probe kernel: one thread per read position, so a wave never waits on a second
+// pass over one read) and a second kernel picks and orders the SMEMs per read:
 //     kt-mer prefix table  ->  suffix-array interval  ->  refine by binary search
 //     on (sa, text)  ->  once one suffix is left, 8-byte compares along the text.
 // That yields the matching statistics MS[i]; position i starts an SMEM iff
@@ -45,19 +47,19 @@ __device__ __forceinline__ uint64_t load8_lds(const uint8_t* base16, int off) {
   return sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
 }
 
-// LCP of the query tail rd[qoff..L) with the text at tp; *less tells whether the
+// LCP of the query tail q[0..cap) with the text at tp; *less tells whether the
 // text suffix sorts before the query (a suffix that has the whole query tail as a
-// prefix is >= it).  At most `cap` characters are compared.  The text bytes are
-// fetched 64 at a time with all eight loads in flight together (one memory round
-// trip per 64 characters instead of one per 8); PROBE first looks at 8 bytes only,
-// which settles most comparisons of a binary search.  The text carries 128 bytes
-// of padding, so the speculative tail of a batch stays inside the allocation.
+// prefix is >= it).  The text bytes are fetched 64 at a time with all eight loads
+// in flight together (one memory round trip per 64 characters instead of one per
+// 8); PROBE first looks at 8 bytes only, which settles most comparisons of a
+// binary search.  Text and read buffers carry 128 bytes of padding, so the
+// speculative tail of a batch stays inside the allocations.
 template <bool PROBE>
-__device__ __forceinline__ int lcp_cmp(const uint8_t* tp, const uint8_t* rd, int qoff, int cap, bool* less) {
+__device__ __forceinline__ int lcp_cmp(const uint8_t* tp, const uint8_t* q, int cap, bool* less) {
   *less = false;
   int o = 0;
   if (PROBE && cap > 0) {
-    const uint64_t tw = load8_global(tp), qw = load8_lds(rd, qoff);
+    const uint64_t tw = load8_global(tp), qw = load8_global(q);
     const uint64_t x = tw ^ qw;
     if (x) {
       const int idx = __builtin_ctzll(x) >> 3;
@@ -77,7 +79,7 @@ __device__ __forceinline__ int lcp_cmp(const uint8_t* tp, const uint8_t* rd, int
     for (int u = 0; u < 8; u++) {
       const int oo = o + 8 * u;
       if (oo < cap) {
-        const uint64_t qw = load8_lds(rd, qoff + oo);
+        const uint64_t qw = load8_global(q + oo);
         const uint64_t x = tw[u] ^ qw;
         if (x) {
           const int idx = __builtin_ctzll(x) >> 3;
@@ -97,10 +99,13 @@ __device__ __forceinline__ int lcp_cmp(const uint8_t* tp, const uint8_t* rd, int
 // longest match of rd[pos..L) in the text: length d and suffix-array interval.
 //   1. kt-mer table: interval of the first kt characters in one probe;
 //   2. one suffix left -> compare along the text;
-//   3. otherwise: lower bound of the whole query tail among the interval's suffixes
-//      (string comparison from offset d), the longest match is the better of the two
-//      neighbours of the insertion point, and the final interval is found by two
-//      more binary searches on "shares >= ms characters".
+//   3. up to 8 suffixes: fetch all their positions, then all their next 8 bytes,
+//      with the loads in flight together; only suffixes that agree on those 8 bytes
+//      are compared further.  The interval of the longest match is the run of
+//      suffixes attaining the maximum (they are adjacent in suffix order);
+//   4. larger intervals (repeats): lower bound of the whole query tail by binary
+//      search, the better of the two neighbours of the insertion point gives the
+//      match length, two more binary searches give the interval.
 __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int pos, int k, int& out_d, uint32_t& out_lo,
                           uint32_t& out_hi) {
   uint32_t lo = 0, hi = (uint32_t)ix.n;
@@ -109,8 +114,9 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
   if (kt <= k) {
     uint32_t code = 0;
     bool acgt = true;
+    const uint64_t w0 = load8_global(rd + pos), w1 = load8_global(rd + pos + 8);  // kt <= 14 characters
     for (int t = 0; t < kt; t++) {
-      const int c = base_code(rd[pos + t]);
+      const int c = base_code((uint8_t)((t < 8 ? (w0 >> (8 * t)) : (w1 >> (8 * (t - 8)))) & 0xff));
       acgt = acgt && (c >= 0);
       code = (code << 2) | (uint32_t)(c & 3);
     }
@@ -123,50 +129,90 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
   }
   if (lo < hi && pos + d < L) {
     const int cap = L - (pos + d);
+    const uint8_t* q = rd + pos + d;
     bool less;
-    if (hi - lo == 1) {
-      d += lcp_cmp<false>(ix.text + ix.sa[lo] + d, rd, pos + d, cap, &less);
-    } else if (rd[pos + d] != 0) {  // a byte outside ACGTN matches nothing: the interval stays at depth d
-      uint32_t a = lo, b = hi;
-      while (a < b) {
-        const uint32_t m = a + ((b - a) >> 1);
-        (void)lcp_cmp<true>(ix.text + ix.sa[m] + d, rd, pos + d, cap, &less);
-        if (less)
-          a = m + 1;
-        else
-          b = m;
-      }
-      int l1 = -1, l2 = -1;
-      if (a > lo) l1 = lcp_cmp<true>(ix.text + ix.sa[a - 1] + d, rd, pos + d, cap, &less);
-      if (a < hi) l2 = lcp_cmp<true>(ix.text + ix.sa[a] + d, rd, pos + d, cap, &less);
-      const int ms = max(l1, l2);
-      if (ms > 0) {
-        uint32_t nlo = a, nhi = a;
-        if (l1 >= ms) {  // leftmost suffix in [lo, a) that still shares ms characters
-          uint32_t x = lo, y = a - 1;
-          while (x < y) {
-            const uint32_t m = x + ((y - x) >> 1);
-            if (lcp_cmp<true>(ix.text + ix.sa[m] + d, rd, pos + d, ms, &less) >= ms)
-              y = m;
-            else
-              x = m + 1;
-          }
-          nlo = x;
+    const uint32_t sz = hi - lo;
+    if (sz == 1) {
+      d += lcp_cmp<false>(ix.text + ix.sa[lo] + d, q, cap, &less);
+    } else if (q[0] != 0) {  // a byte outside ACGTN matches nothing: the interval stays at depth d
+      if (sz <= 8) {
+        uint32_t sav[8];
+        uint64_t tw[8];
+        int lc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sav[u] = (lo + u < hi) ? ix.sa[lo + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) tw[u] = load8_global(ix.text + sav[u] + d);
+        const uint64_t qw = load8_global(q);
+        int ms = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const uint64_t x = tw[u] ^ qw;
+          int l = x ? (__builtin_ctzll(x) >> 3) : 8;
+          l = min(l, cap);
+          if (lo + u >= hi) l = -1;
+          lc[u] = l;
         }
-        if (l2 >= ms) {  // one past the rightmost suffix in [a, hi) that shares ms characters
-          uint32_t x = a + 1, y = hi;
-          while (x < y) {
-            const uint32_t m = x + ((y - x) >> 1);
-            if (lcp_cmp<true>(ix.text + ix.sa[m] + d, rd, pos + d, ms, &less) >= ms)
-              x = m + 1;
-            else
-              y = m;
-          }
-          nhi = x;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (lc[u] == 8 && cap > 8) lc[u] = 8 + lcp_cmp<false>(ix.text + sav[u] + d + 8, q + 8, cap - 8, &less);
+          ms = max(ms, lc[u]);
         }
-        lo = nlo;
-        hi = nhi;
-        d += ms;
+        if (ms > 0) {
+          uint32_t nlo = hi, nhi = lo;
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            if (lc[u] == ms) {
+              nlo = min(nlo, lo + u);
+              nhi = max(nhi, lo + u + 1);
+            }
+          }
+          lo = nlo;
+          hi = nhi;
+          d += ms;
+        }
+      } else {
+        uint32_t a = lo, b = hi;
+        while (a < b) {
+          const uint32_t m = a + ((b - a) >> 1);
+          (void)lcp_cmp<true>(ix.text + ix.sa[m] + d, q, cap, &less);
+          if (less)
+            a = m + 1;
+          else
+            b = m;
+        }
+        int l1 = -1, l2 = -1;
+        if (a > lo) l1 = lcp_cmp<true>(ix.text + ix.sa[a - 1] + d, q, cap, &less);
+        if (a < hi) l2 = lcp_cmp<true>(ix.text + ix.sa[a] + d, q, cap, &less);
+        const int ms = max(l1, l2);
+        if (ms > 0) {
+          uint32_t nlo = a, nhi = a;
+          if (l1 >= ms) {  // leftmost suffix in [lo, a) that still shares ms characters
+            uint32_t x = lo, y = a - 1;
+            while (x < y) {
+              const uint32_t m = x + ((y - x) >> 1);
+              if (lcp_cmp<true>(ix.text + ix.sa[m] + d, q, ms, &less) >= ms)
+                y = m;
+              else
+                x = m + 1;
+            }
+            nlo = x;
+          }
+          if (l2 >= ms) {  // one past the rightmost suffix in [a, hi) that shares ms characters
+            uint32_t x = a + 1, y = hi;
+            while (x < y) {
+              const uint32_t m = x + ((y - x) >> 1);
+              if (lcp_cmp<true>(ix.text + ix.sa[m] + d, q, ms, &less) >= ms)
+                x = m + 1;
+              else
+                y = m;
+            }
+            nhi = x;
+          }
+          lo = nlo;
+          hi = nhi;
+          d += ms;
+        }
       }
     }
   }
@@ -175,56 +221,80 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
   out_hi = hi;
 }
 
-__global__ __launch_bounds__(256) void seed_kernel(SeedParams p) {
+// upper-case + sanitise the batch once (reference src/aligner.rs:125); both the
+// probe kernel and the extend kernel read this copy
+__global__ void sanitize_kernel(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = sanitize_base(in[i]);
+  else if (i < n_padded)
+    out[i] = 0;
+}
+
+// matching statistics: one thread per (read, position)
+__global__ __launch_bounds__(256) void seed_probe_kernel(SeedParams p) {
+  const uint64_t item = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t P = p.pos_per_read;
+  const uint64_t read = item / P;
+  if (read >= p.reads.n_reads) return;
+  const int pos = (int)(item - read * P);
+  const uint64_t r0 = p.reads.offsets[read];
+  const int L = (int)(p.reads.offsets[read + 1] - r0);
+  const int k = (int)p.min_seed_len;
+  int d = 0;
+  uint32_t lo = 0, hi = 0;
+  if (pos + k <= L) ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
+  p.ms_end[item] = (uint16_t)((d >= k) ? pos + d : 0);
+  p.ms_lo[item] = lo;
+  p.ms_hi[item] = hi;
+}
+
+// per read: SMEM selection and ordering, one read per wavefront
+__global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
-  const uint32_t lcap = (p.max_read_len + 31u) & ~15u;  // >= L + 16, multiple of 16
-  const uint32_t per_wave = lcap * 26;
+  const uint32_t lcap = (p.max_read_len + 31u) & ~15u;
+  const uint32_t per_wave = lcap * 16;
   uint8_t* base = smem + (size_t)wave * per_wave;
-  uint8_t* rd = base;                              // lcap
-  uint32_t* a_lo = (uint32_t*)(base + lcap);       // lcap * 4
-  uint32_t* a_hi = a_lo + lcap;                    // lcap * 4
-  uint32_t* s_lo = a_hi + lcap;                    // lcap * 4
-  uint32_t* s_hi = s_lo + lcap;                    // lcap * 4
-  uint16_t* a_end = (uint16_t*)(s_hi + lcap);      // lcap * 2
-  uint16_t* s_pos = a_end + lcap;                  // lcap * 2
-  uint16_t* s_len = s_pos + lcap;                  // lcap * 2
-  uint16_t* s_em = s_len + lcap;                   // lcap * 2
+  uint32_t* s_lo = (uint32_t*)base;            // lcap * 4
+  uint32_t* s_hi = s_lo + lcap;                // lcap * 4
+  uint16_t* a_end = (uint16_t*)(s_hi + lcap);  // lcap * 2
+  uint16_t* s_pos = a_end + lcap;              // lcap * 2
+  uint16_t* s_len = s_pos + lcap;              // lcap * 2
+  uint16_t* s_em = s_len + lcap;               // lcap * 2
 
   const int k = (int)p.min_seed_len;
+  const uint32_t P = p.pos_per_read;
   unsigned long long c_smems = 0, c_hits = 0;
+  constexpr unsigned QCHUNK = 8;
+  unsigned q_next = 0, q_end = 0;
   for (;;) {
-    unsigned idx = 0;
-    if (lane == 0) idx = atomicAdd(p.queue, 1u);
-    idx = (unsigned)bcast_first((int)idx);
-    if (idx >= p.reads.n_reads) break;
-    const uint64_t r0 = p.reads.offsets[idx];
-    const int L = (int)(p.reads.offsets[idx + 1] - r0);
-    for (int t = lane; t < (int)lcap; t += 64) rd[t] = (t < L) ? sanitize_base(p.reads.bases[r0 + t]) : (uint8_t)0;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-
-    // matching statistics, one position per lane
-    for (int b0 = 0; b0 < L; b0 += 64) {
-      const int pos = b0 + lane;
-      if (pos < L) {
-        int d = 0;
-        uint32_t lo = 0, hi = 0;
-        if (pos + k <= L) ms_search(p.ix, rd, L, pos, k, d, lo, hi);
-        a_end[pos] = (uint16_t)((d >= k) ? pos + d : 0);
-        a_lo[pos] = lo;
-        a_hi[pos] = hi;
-      }
+    if (q_next == q_end) {
+      unsigned g = 0;
+      if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
+      g = (unsigned)bcast_first((int)g);
+      if (g >= p.reads.n_reads) break;
+      q_next = g;
+      q_end = min(g + QCHUNK, (unsigned)p.reads.n_reads);
     }
+    const unsigned idx = q_next++;
+    const uint64_t r0 = uload(&p.reads.offsets[idx]);
+    const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
+    const int npos = max(L - k + 1, 0);  // positions that were probed
+    const uint64_t item0 = (uint64_t)idx * P;
+#pragma unroll 1
+    for (int t = lane; t < npos; t += 64) a_end[t] = p.ms_end[item0 + t];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
     // SMEM starts: end[i] > end[i-1]; compacted in start order
     int n_sm = 0;
-    for (int b0 = 0; b0 < L; b0 += 64) {
+#pragma unroll 1
+    for (int b0 = 0; b0 < npos; b0 += 64) {
       const int pos = b0 + lane;
       bool is = false;
       int e = 0;
-      if (pos < L) {
+      if (pos < npos) {
         e = a_end[pos];
         const int prev = pos > 0 ? (int)a_end[pos - 1] : 0;
         is = e > 0 && e > prev;
@@ -234,8 +304,8 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedParams p) {
         const int at = n_sm + __popcll(mask & ((1ull << lane) - 1ull));
         s_pos[at] = (uint16_t)pos;
         s_len[at] = (uint16_t)(e - pos);
-        s_lo[at] = a_lo[pos];
-        s_hi[at] = a_hi[pos];
+        s_lo[at] = p.ms_lo[item0 + pos];
+        s_hi[at] = p.ms_hi[item0 + pos];
       }
       n_sm += __popcll(mask);
     }
@@ -243,7 +313,7 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedParams p) {
 
     // emission order of FMDIndex::all_smems: walk i0; the SMEMs covering i0 come
     // out by descending start; i0 jumps to the furthest end (or to the next start)
-    {
+    if (n_sm > 1) {
       int t = 0, em = 0, i0 = 0;
       while (t < n_sm) {
         const int st = s_pos[t];
@@ -256,14 +326,17 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedParams p) {
         i0 = (int)s_pos[u - 1] + (int)s_len[u - 1];
         t = u;
       }
+    } else if (lane == 0) {
+      s_em[0] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-
     // order: length descending, then emission index descending
     unsigned long long base_out = 0;
-    if (lane == 0 && n_sm > 0) base_out = atomicAdd(p.cursor, (unsigned long long)n_sm);
-    base_out = ((unsigned long long)(unsigned)bcast_first((int)(base_out >> 32)) << 32) |
-               (unsigned)bcast_first((int)(base_out & 0xffffffffu));
+    if (n_sm > 0) {
+      if (lane == 0) base_out = atomicAdd(p.cursor, (unsigned long long)n_sm);
+      base_out = ((unsigned long long)(unsigned)bcast_first((int)(base_out >> 32)) << 32) |
+                 (unsigned)bcast_first((int)(base_out & 0xffffffffu));
+    }
     const bool fits = base_out + (unsigned long long)n_sm <= p.smem_cap;
     unsigned long long hits = 0;
     for (int t0 = 0; t0 < n_sm; t0 += 64) {
@@ -330,16 +403,28 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
 
 size_t seed_lds_bytes(uint32_t max_read_len) {
   const uint32_t lcap = (max_read_len + 31u) & ~15u;
-  return 4 * (size_t)lcap * 26;
+  return 4 * (size_t)lcap * 16;
+}
+
+hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded, hipStream_t s) {
+  if (n_padded == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::sanitize_kernel, dim3((unsigned)((n_padded + 255) / 256)), dim3(256), 0, s, in, out, n, n_padded);
+  return hipGetLastError();
 }
 
 hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s) {
-  const size_t lds = seed_lds_bytes(p.max_read_len);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)dev::seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const uint64_t items = p.reads.n_reads * (uint64_t)p.pos_per_read;
+  if (items) {
+    hipLaunchKernelGGL(dev::seed_probe_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(dev::seed_kernel, dim3(n_blocks), dim3(256), lds, s, p);
+  const size_t lds = seed_lds_bytes(p.max_read_len);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)dev::seed_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(dev::seed_select_kernel, dim3(n_blocks), dim3(256), lds, s, p);
   return hipGetLastError();
 }
 

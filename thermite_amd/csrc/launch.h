@@ -30,7 +30,7 @@ hipError_t launch_wave_prims(const int* in, int* out, hipStream_t s);
 
 // ---- read-level pipeline ----
 struct ReadBatch {
-  const uint8_t* bases;     // raw reads (not yet upper-cased), device
+  const uint8_t* bases;     // upper-cased, sanitised reads (bytes outside ACGTN -> 0), 128 B zero padding, device
   const uint64_t* offsets;  // [n_reads+1]
   uint64_t n_reads;
 };
@@ -40,6 +40,10 @@ struct SeedParams {
   ReadBatch reads;
   uint32_t min_seed_len;
   uint32_t max_read_len;       // LDS sizing
+  uint32_t pos_per_read;       // max_read_len - min_seed_len + 1 (>= 1): probe slots per read
+  uint16_t* ms_end;            // [n_reads * pos_per_read] end of the longest match from this position (0: < k)
+  uint32_t* ms_lo;             // its suffix-array interval
+  uint32_t* ms_hi;
   Smem* smems;                 // pool
   uint64_t smem_cap;           // pool capacity (entries)
   unsigned long long* cursor;  // bump allocator head (entries), zeroed before launch
@@ -52,6 +56,7 @@ struct SeedParams {
 };
 size_t seed_lds_bytes(uint32_t max_read_len);
 hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s);
+hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded, hipStream_t s);
 
 // expand SMEMs into Mem lists (thm_smems_batch)
 struct ExpandParams {

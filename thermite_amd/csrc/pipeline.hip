@@ -51,12 +51,24 @@ int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
   if (a->smem_cap < n * 4 + 4096) a->smem_cap = n * 4 + 4096;
   HIPCHK(a, a->s_smems.ensure(a->smem_cap * sizeof(Smem)));
   a->smem_cap = std::max<uint64_t>(a->smem_cap, a->s_smems.cap / sizeof(Smem));
+  // to_ascii_uppercase (src/aligner.rs:125) + sanitising, once per run for both kernels
+  HIPCHK(a, a->r_san.ensure(a->n_bases + 256));
+  HIPCHK(a, launch_sanitize(a->r_bases.as<uint8_t>(), a->r_san.as<uint8_t>(), a->n_bases, a->n_bases + 128, s));
+  const uint32_t P = (a->max_read_len >= min_seed_len) ? a->max_read_len - min_seed_len + 1 : 1;
+  const uint64_t items = n * (uint64_t)P;
+  HIPCHK(a, a->s_ms_end.ensure(items * 2 + 64));
+  HIPCHK(a, a->s_ms_lo.ensure(items * 4 + 64));
+  HIPCHK(a, a->s_ms_hi.ensure(items * 4 + 64));
   int rc = reset_queue(a);
   if (rc != THM_OK) return rc;
   HIPCHK(a, hipMemsetAsync(a->d_cursors.p, 0, 64, s));
   SeedParams sp;
   sp.ix = a->dix->view;
-  sp.reads.bases = a->r_bases.as<uint8_t>();
+  sp.pos_per_read = P;
+  sp.ms_end = a->s_ms_end.as<uint16_t>();
+  sp.ms_lo = a->s_ms_lo.as<uint32_t>();
+  sp.ms_hi = a->s_ms_hi.as<uint32_t>();
+  sp.reads.bases = a->r_san.as<uint8_t>();
   sp.reads.offsets = a->r_offsets.as<uint64_t>();
   sp.reads.n_reads = n;
   sp.min_seed_len = min_seed_len;
@@ -112,7 +124,7 @@ int enqueue_run(thm_aligner* a) {
 
   ExtendParams ep;
   ep.ix = a->dix->view;
-  ep.reads.bases = a->r_bases.as<uint8_t>();
+  ep.reads.bases = a->r_san.as<uint8_t>();
   ep.reads.offsets = a->r_offsets.as<uint64_t>();
   ep.reads.n_reads = n;
   ep.opts = a->opts;
