@@ -269,6 +269,8 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
   unsigned long long c_smems = 0, c_hits = 0;
   constexpr unsigned QCHUNK = 8;
   unsigned q_next = 0, q_end = 0;
+  unsigned long long pool_off = 0;
+  unsigned pool_left = 0;
   for (;;) {
     if (q_next == q_end) {
       unsigned g = 0;
@@ -331,11 +333,24 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     // order: length descending, then emission index descending
+    // the SMEM pool is handed out to waves in slices (one atomic per slice: a single
+    // hot word serves only ~88 M returning atomics per second)
     unsigned long long base_out = 0;
     if (n_sm > 0) {
-      if (lane == 0) base_out = atomicAdd(p.cursor, (unsigned long long)n_sm);
-      base_out = ((unsigned long long)(unsigned)bcast_first((int)(base_out >> 32)) << 32) |
-                 (unsigned)bcast_first((int)(base_out & 0xffffffffu));
+      if ((unsigned)n_sm > pool_left) {
+        const unsigned grab = max(256u, (unsigned)n_sm);
+        unsigned long long g = 0;
+        if (lane == 0) g = atomicAdd(p.cursor, (unsigned long long)grab);
+        g = ((unsigned long long)(unsigned)bcast_first((int)(g >> 32)) << 32) | (unsigned)bcast_first((int)(g & 0xffffffffu));
+        pool_off = g;
+        pool_left = (g + grab <= p.smem_cap) ? grab : 0u;
+        if (pool_left == 0) pool_off = p.smem_cap;  // forces !fits below
+      }
+      base_out = pool_off;
+      if (pool_left >= (unsigned)n_sm) {
+        pool_off += (unsigned)n_sm;
+        pool_left -= (unsigned)n_sm;
+      }
     }
     const bool fits = base_out + (unsigned long long)n_sm <= p.smem_cap;
     unsigned long long hits = 0;

@@ -48,7 +48,8 @@ int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
   HIPCHK(a, a->s_hits.ensure((n + 1) * 8));
   HIPCHK(a, a->s_cand_off.ensure((n + 2) * 8));
   HIPCHK(a, a->scan_tmp.ensure(scan_tmp_entries(n + 1) * 8 + 64));
-  if (a->smem_cap < n * 4 + 4096) a->smem_cap = n * 4 + 4096;
+  // typical: 1-2 SMEMs per read; waves take the pool in 256-entry slices, hence the fixed slack
+  if (a->smem_cap < n * 4 + (4u << 20)) a->smem_cap = n * 4 + (4u << 20);
   HIPCHK(a, a->s_smems.ensure(a->smem_cap * sizeof(Smem)));
   a->smem_cap = std::max<uint64_t>(a->smem_cap, a->s_smems.cap / sizeof(Smem));
   // to_ascii_uppercase (src/aligner.rs:125) + sanitising, once per run for both kernels
