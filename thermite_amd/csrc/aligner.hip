@@ -57,8 +57,10 @@ static int get_dev_copy(thm_aligner* a) {
     if (e == hipSuccess) e = hipMemsetAsync(d->tx_seq.p, '$', 16, s);
     if (e == hipSuccess && !ix->tx_seq.empty())
       e = hipMemcpyAsync(d->tx_seq.as<uint8_t>() + 16, ix->tx_seq.data(), ix->tx_seq.size(), hipMemcpyHostToDevice, s);
-    up(d->exon_tree, ix->exon_tree);
-    up(d->gene_tree, ix->gene_tree);
+    up(d->exon_grid_off, ix->exon_grid_off);
+    up(d->exon_grid, ix->exon_grid);
+    up(d->gene_grid_off, ix->gene_grid_off);
+    up(d->gene_grid, ix->gene_grid);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
       free_dev_copy(d);
@@ -75,8 +77,10 @@ static int get_dev_copy(thm_aligner* a) {
     v.exons = d->exons.as<thm_exon>();
     v.exon_txoff = d->exon_txoff.as<uint64_t>();
     v.tx_seq = d->tx_seq.as<uint8_t>() + 16;
-    v.exon_tree = d->exon_tree.as<TreeNode>();
-    v.gene_tree = d->gene_tree.as<TreeNode>();
+    v.exon_grid_off = d->exon_grid_off.as<uint32_t>();
+    v.exon_grid = d->exon_grid.as<GridEntry>();
+    v.gene_grid_off = d->gene_grid_off.as<uint32_t>();
+    v.gene_grid = d->gene_grid.as<GridEntry>();
     v.n = ix->n;
     v.n_refs = (uint32_t)ix->refs.size();
     v.n_txs = (uint32_t)ix->txs.size();

@@ -38,7 +38,7 @@ struct DBuf {
 
 struct thm_index::DevCopy {
   int device = -1;
-  DBuf text, sa, lut, refs, name_rank, txs, exons, exon_txoff, tx_seq, exon_tree, gene_tree;
+  DBuf text, sa, lut, refs, name_rank, txs, exons, exon_txoff, tx_seq, exon_grid_off, exon_grid, gene_grid_off, gene_grid;
   thm::DeviceIndex view;
 };
 
@@ -48,7 +48,7 @@ inline void free_dev_copy(thm_index::DevCopy* d) {
   (void)hipGetDevice(&cur);
   (void)hipSetDevice(d->device);
   DBuf* all[] = {&d->text, &d->sa,         &d->lut,    &d->refs,      &d->name_rank, &d->txs,
-                 &d->exons, &d->exon_txoff, &d->tx_seq, &d->exon_tree, &d->gene_tree};
+                 &d->exons, &d->exon_txoff, &d->tx_seq, &d->exon_grid_off, &d->exon_grid, &d->gene_grid_off, &d->gene_grid};
   for (DBuf* b : all) b->release();
   (void)hipSetDevice(cur);
   delete d;

@@ -119,6 +119,45 @@ struct Avl {
   }
 };
 
+// ranks in the order IntervalTree::find visits nodes: node, right subtree, left subtree
+void preorder_ranks(const std::vector<TreeNode>& nd, int32_t root, std::vector<uint32_t>& rank) {
+  rank.assign(nd.size(), 0);
+  std::vector<int32_t> st;
+  if (root >= 0) st.push_back(root);
+  uint32_t r = 0;
+  while (!st.empty()) {
+    const int32_t x = st.back();
+    st.pop_back();
+    rank[x] = r++;
+    if (nd[x].left >= 0) st.push_back(nd[x].left);    // popped after the right child
+    if (nd[x].right >= 0) st.push_back(nd[x].right);
+  }
+}
+
+void build_grid(const std::vector<TreeNode>& nd, int32_t root, uint64_t n, std::vector<uint32_t>& off,
+                std::vector<GridEntry>& entries) {
+  std::vector<uint32_t> rank;
+  preorder_ranks(nd, root, rank);
+  const uint64_t nbins = (n >> GRID_SHIFT) + 1;
+  off.assign(nbins + 1, 0);
+  for (const TreeNode& t : nd) {
+    if (t.end <= t.start) continue;  // an empty interval overlaps nothing
+    for (uint64_t b = t.start >> GRID_SHIFT; b <= ((t.end - 1) >> GRID_SHIFT) && b < nbins; b++) off[b + 1]++;
+  }
+  for (uint64_t b = 0; b < nbins; b++) off[b + 1] += off[b];
+  entries.assign(off[nbins], GridEntry{0, 0, 0, 0});
+  std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+  for (size_t x = 0; x < nd.size(); x++) {
+    const TreeNode& t = nd[x];
+    if (t.end <= t.start) continue;
+    for (uint64_t b = t.start >> GRID_SHIFT; b <= ((t.end - 1) >> GRID_SHIFT) && b < nbins; b++)
+      entries[fill[b]++] = GridEntry{(uint32_t)t.start, (uint32_t)t.end, t.value, (rank[x] << 8) | (uint32_t)(b & 0xff)};
+  }
+  for (uint64_t b = 0; b < nbins; b++)
+    std::sort(entries.begin() + off[b], entries.begin() + off[b + 1],
+              [](const GridEntry& a, const GridEntry& c) { return a.rank < c.rank; });
+}
+
 inline int base_code(uint8_t c) {
   switch (c) {
     case 'A': return 0;
@@ -294,6 +333,8 @@ int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_re
     ix->gene_tree.swap(a.nd);
     ix->gene_root = root;
   }
+  build_grid(ix->exon_tree, ix->exon_root, n, ix->exon_grid_off, ix->exon_grid);
+  build_grid(ix->gene_tree, ix->gene_root, n, ix->gene_grid_off, ix->gene_grid);
   ix->dev_mu = new std::mutex();
   *out = ix;
   return THM_OK;

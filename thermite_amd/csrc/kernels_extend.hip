@@ -109,6 +109,80 @@ enum { PS_SETUP = 0, PS_STAGE = 1, PS_DP = 2, PS_TRACEBACK = 3, PS_TREE = 4, PS_
   } while (0)
 #endif
 
+// One query of an interval grid (thermite_internal.h): the intervals overlapping
+// [qs, qe) come out in IntervalTree::find order, i.e. by ascending pre-order rank.
+// Up to 64 candidate entries sit one per lane in registers; larger candidate sets
+// (dense loci) are re-read from memory on every step.
+struct GridQuery {
+  const GridEntry* ent;  // candidates [0, cnt)
+  uint32_t cnt;
+  uint32_t qs, qe, b0;
+  int last;     // rank of the interval yielded last (-1 before the first)
+  int my_rank;  // this lane's candidate: its rank if it overlaps and is the primary copy, else -1
+  uint32_t my_val;
+};
+__device__ __forceinline__ int grid_entry_rank(const GridEntry& e, uint32_t qs, uint32_t qe, uint32_t b0) {
+  const bool overlap = qs < e.end && e.start < qe;
+  const uint32_t home = max(b0, e.start >> GRID_SHIFT);  // first queried bin this interval is listed in
+  const bool primary = (e.rank & 0xffu) == (home & 0xffu);
+  return (overlap && primary) ? (int)(e.rank >> 8) : -1;
+}
+__device__ void grid_begin(GridQuery& g, const uint32_t* off, const GridEntry* entries, uint32_t qs, uint32_t qe) {
+  const uint32_t b0 = qs >> GRID_SHIFT, b1 = (qe > qs ? qe - 1 : qs) >> GRID_SHIFT;
+  const uint32_t e0 = uload(&off[b0]), e1 = uload(&off[b1 + 1]);
+  g.ent = entries + e0;
+  g.cnt = e1 - e0;
+  g.qs = qs;
+  g.qe = qe;
+  g.b0 = b0;
+  g.last = -1;
+  g.my_rank = -1;
+  g.my_val = 0;
+  if (g.cnt <= 64 && (uint32_t)lane_id() < g.cnt) {
+    const GridEntry e = g.ent[lane_id()];
+    g.my_rank = grid_entry_rank(e, qs, qe, b0);
+    g.my_val = e.value;
+  }
+}
+// next overlapping interval in yield order; false when exhausted
+__device__ bool grid_next(GridQuery& g, uint32_t& value) {
+  const int BIG = 0x0fffffff;
+  if (g.cnt == 0) return false;
+  if (g.cnt <= 64) {
+    const int cand = (g.my_rank > g.last) ? g.my_rank : BIG;
+    const int best = wave_min(cand);
+    if (best == BIG) return false;
+    const unsigned long long m = __ballot(g.my_rank == best);
+    value = (uint32_t)__builtin_amdgcn_readlane((int)g.my_val, __builtin_ctzll(m));
+    g.last = best;
+    return true;
+  }
+  int best = BIG;
+  uint32_t bval = 0;
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < g.cnt; c0 += 64) {
+    const uint32_t i = c0 + (uint32_t)lane_id();
+    int r = -1;
+    uint32_t v = 0;
+    if (i < g.cnt) {
+      const GridEntry e = g.ent[i];
+      r = grid_entry_rank(e, g.qs, g.qe, g.b0);
+      v = e.value;
+    }
+    const int cand = (r > g.last) ? r : BIG;
+    const int cb = wave_min(cand);
+    if (cb < best) {
+      best = cb;
+      const unsigned long long m = __ballot(cand == cb);
+      bval = (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_ctzll(m));
+    }
+  }
+  if (best == BIG) return false;
+  value = bval;
+  g.last = best;
+  return true;
+}
+
 struct Path {
   int score, xstart, xend, nops;
   int ystart, yend;  // in the coordinates r / lo_abs were given in
@@ -481,9 +555,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           uint32_t best_tx = 0;
           uint8_t* cur_buf = c.pb;
           uint8_t* best_buf = c.pc;
-          int sp = 0;
           bool genome_done = false;
           LrMemo gmemo, tmemo;
+          GridQuery eg;
           for (;;) {
             int win0, lo_abs, hi_abs, t_r;
             int t_q, t_len;
@@ -502,36 +576,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               t_len = len;
               buf = c.pa;
             } else {
-              // next interval IntervalTree::find yields: pop; if q.start < node.max push left;
-              // if q.end > node.start push right and yield on overlap
-              bool found = false;
-              while (sp > 0 && !found) {
-                const int ni = bcast_first(c.stack[--sp]);  // uniform: the node comes through the scalar cache
-                wfence();
-                const TreeNode nd = uload(&ix.exon_tree[ni]);
-                if (qs < (uint32_t)nd.max) {
-                  if (sp >= 60) {
-                    c.fault |= FAULT_INTERNAL;
-                    sp = 0;
-                    break;
-                  }
-                  if (nd.left >= 0) {
-                    if (lane == 0) c.stack[sp] = nd.left;
-                    sp++;
-                  }
-                  if (qe > (uint32_t)nd.start) {
-                    if (nd.right >= 0) {
-                      if (lane == 0) c.stack[sp] = nd.right;
-                      sp++;
-                    }
-                    if (qs < (uint32_t)nd.end && (uint32_t)nd.start < qe) {
-                      found = true;
-                      tx_idx = nd.value;
-                    }
-                  }
-                }
-                wfence();
-              }
+              // next interval exon_to_tx.find would yield (interval grid, same order)
+              const bool found = grid_next(eg, tx_idx);
               PROF_MARK(c, PS_TREE);
               if (!found) break;
               const thm_tx tx = uload(&ix.txs[tx_idx]);
@@ -659,11 +705,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
             if (!genome_done) {
               gx = pth;
               genome_done = true;
-              if (ix.exon_root >= 0) {
-                if (lane == 0) c.stack[0] = ix.exon_root;
-                sp = 1;
-              }
-              wfence();
+              grid_begin(eg, ix.exon_grid_off, ix.exon_grid, qs, qe);
             } else {
               if (!have_best || pth.score > best.score) {  // strictly better (:249)
                 have_best = true;
@@ -712,35 +754,12 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               g_ny = lift_markers(c, ix, uload(&ix.txs[best_tx]), best_buf, best.nops, best.xend < L, best.ystart, best.yend, cy0, cy1);
             } else {
               // first interval gene_intervals.find yields (:283-288, :306); only reached in intron mode
-              const uint32_t gs = (uint32_t)cy0, ge_ = (uint32_t)cy1;
-              int gsp = 0;
-              if (ix.gene_root >= 0) {
-                if (lane == 0) c.stack[0] = ix.gene_root;
-                gsp = 1;
-              }
-              wfence();
-              while (gsp > 0) {
-                const int ni = bcast_first(c.stack[--gsp]);
-                wfence();
-                const TreeNode nd = uload(&ix.gene_tree[ni]);
-                if (gs < (uint32_t)nd.max) {
-                  if (nd.left >= 0 && gsp < 60) {
-                    if (lane == 0) c.stack[gsp] = nd.left;
-                    gsp++;
-                  }
-                  if (ge_ > (uint32_t)nd.start) {
-                    if (nd.right >= 0 && gsp < 60) {
-                      if (lane == 0) c.stack[gsp] = nd.right;
-                      gsp++;
-                    }
-                    if (gs < (uint32_t)nd.end && (uint32_t)nd.start < ge_) {
-                      aln_type = THM_ALN_INTRONIC;
-                      type_idx = nd.value;
-                      break;
-                    }
-                  }
-                }
-                wfence();
+              GridQuery gg;
+              grid_begin(gg, ix.gene_grid_off, ix.gene_grid, (uint32_t)cy0, (uint32_t)cy1);
+              uint32_t gene = 0;
+              if (grid_next(gg, gene)) {
+                aln_type = THM_ALN_INTRONIC;
+                type_idx = gene;
               }
               PROF_MARK(c, PS_TREE);
             }

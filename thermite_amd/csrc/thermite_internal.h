@@ -30,6 +30,18 @@ struct TreeNode {
 };
 static_assert(sizeof(TreeNode) == 40, "TreeNode layout");
 
+// Interval grid: the device-side form of an interval tree.  The text is cut into
+// bins of 2^GRID_SHIFT symbols; a bin lists every interval overlapping it, sorted
+// by the interval's rank in the (node, right, left) pre-order of the AVL tree --
+// the order bio's IntervalTree::find yields overlapping intervals in (pruning
+// only skips subtrees, it never reorders).  A query reads one or two adjacent
+// bins in two memory round trips instead of walking ~log2(n) dependent nodes.
+constexpr uint32_t GRID_SHIFT = 10;
+struct GridEntry {
+  uint32_t start, end, value;
+  uint32_t rank;  // (pre-order rank << 8) | (bin & 0xff): the low byte tells the copies of one interval apart
+};
+
 // k-mer prefix table entry: suffix-array interval of one ACGT-only kt-mer
 struct LutEntry {
   uint32_t lo, hi;
@@ -46,8 +58,10 @@ struct DeviceIndex {
   const thm_exon* exons;
   const uint64_t* exon_txoff;  // per exon: offset of its first base in the transcript
   const uint8_t* tx_seq;
-  const TreeNode* exon_tree;
-  const TreeNode* gene_tree;
+  const uint32_t* exon_grid_off;  // [n_bins + 1]
+  const GridEntry* exon_grid;
+  const uint32_t* gene_grid_off;
+  const GridEntry* gene_grid;
   uint64_t n;
   uint32_t n_refs, n_txs;
   int32_t exon_root, gene_root;
@@ -84,6 +98,8 @@ struct thm_index {
   std::vector<thm_span> genes;
   std::vector<thm::TreeNode> exon_tree, gene_tree;
   int32_t exon_root = -1, gene_root = -1;
+  std::vector<uint32_t> exon_grid_off, gene_grid_off;
+  std::vector<thm::GridEntry> exon_grid, gene_grid;
   uint64_t n = 0;
   // per-device uploaded copy (guarded by dev_mu)
   struct DevCopy;
