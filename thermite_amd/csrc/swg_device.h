@@ -169,8 +169,14 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
     Dv[c] = (b == 0) ? 0 : b * ge + go;
     Cv[c] = (b == 0) ? 0 : MIN_SCORE;
   }
-  int best = 0, best_i = 0, best_j = 0;  // per lane; reference max_score starts at 0
+  // Running maximum (reference max_score, starts at 0) and where it was first reached.
+  // Every rise is by exactly +1, so the first cell attaining the final maximum lies in the
+  // last column that raised it, at the lowest improving row of that column.
   int run_max = 0;
+  int best_j = 0, best_top = 0;
+  unsigned long long best_mask[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; c++) best_mask[c] = 0;
   bool finished = false;
   unsigned long long* tr = trace + (size_t)CPL * 2;  // column 1
 
@@ -202,7 +208,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         lane_tot = max(lane_tot, key[c]);
       }
       int run = wave_excl_max_scan_fast(lane_tot);
-      unsigned long long m_imp = 0, m_alive = 0;
+      unsigned long long m_imp = 0, m_alive = 0, m_c[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
@@ -211,18 +217,15 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         run = max(run, key[c]);
         const int dp = max(d[c], Cn[c]);
         const int Dn = max(dp, R);
-        const int dir = (Dn == d[c]) ? ((xc[c] == yc) ? OPK_MATCH : OPK_SUBST) : ((Dn == Cn[c]) ? OPK_DEL : OPK_INS);
-        const unsigned long long lo = __ballot((dir & 1) != 0);
-        const unsigned long long hi = __ballot((dir & 2) != 0);
+        // direction bits (Match 0, Subst 1, Del 2, Ins 3; priority diag > Del > Ins, reference :226-240)
+        const unsigned long long hi = __ballot(Dn != d[c]);
+        const unsigned long long lo = (~hi & ~__ballot(xc[c] == yc)) | (hi & __ballot(Dn != Cn[c]));
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
           tr[c * 2 + 1] = hi;
         }
-        const bool better = valid && (Dn > best);
-        best = better ? Dn : best;
-        best_i = better ? b : best_i;
-        best_j = better ? j : best_j;
-        m_imp |= __ballot(valid && Dn > run_max);
+        m_c[c] = __ballot(valid && Dn > run_max);
+        m_imp |= m_c[c];
         m_alive |= __ballot(valid && (Dn + (xlen - b) > run_max));
         Dv[c] = valid ? Dn : Dv[c];
         Cv[c] = valid ? Cn[c] : Cv[c];
@@ -230,7 +233,13 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
       tr += CPL * 2;
       res.cells += (unsigned)rows1;
       res.cols += 1;
-      if (m_imp) run_max += MATCH_SCORE;
+      if (m_imp) {
+        run_max += MATCH_SCORE;
+        best_j = j;
+        best_top = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) best_mask[c] = m_c[c];
+      }
       // reference :110: with x_drop >= band_width the X-drop test cannot fire in
       // phase 1; the early exit is ours (see above)
       res.jmax = j;
@@ -274,7 +283,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         lane_tot = max(lane_tot, key[c]);
       }
       int run = wave_excl_max_scan_fast(lane_tot);
-      unsigned long long m_imp = 0, m_alive = 0, m_x = 0;
+      unsigned long long m_imp = 0, m_alive = 0, m_x = 0, m_c[CPL];
       const int xfloor = run_max - xd;  // tested against the updated run_max below
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
@@ -285,18 +294,14 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         run = max(run, key[c]);
         const int dp = max(d[c], Cn[c]);
         const int Dn = max(dp, R);
-        const int dir = (Dn == d[c]) ? ((xc[c] == yc) ? OPK_MATCH : OPK_SUBST) : ((Dn == Cn[c]) ? OPK_DEL : OPK_INS);
-        const unsigned long long lo = __ballot((dir & 1) != 0);
-        const unsigned long long hi = __ballot((dir & 2) != 0);
+        const unsigned long long hi = __ballot(Dn != d[c]);
+        const unsigned long long lo = (~hi & ~__ballot(xc[c] == yc)) | (hi & __ballot(Dn != Cn[c]));
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
           tr[c * 2 + 1] = hi;
         }
-        const bool better = valid && (Dn > best);
-        best = better ? Dn : best;
-        best_i = better ? i : best_i;
-        best_j = better ? j : best_j;
-        m_imp |= __ballot(valid && Dn > run_max);
+        m_c[c] = __ballot(valid && Dn > run_max);
+        m_imp |= m_c[c];
         m_x |= __ballot(valid && Dn >= xfloor);  // X-drop survivors (only consulted when nothing improved)
         m_alive |= __ballot(valid && (Dn + (xlen - i) > run_max));
         Dv[c] = valid ? Dn : Dv[c];
@@ -306,6 +311,10 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
       res.cells += (unsigned)(rows_end - top);
       if (m_imp) {
         run_max += MATCH_SCORE;
+        best_j = j;
+        best_top = top;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) best_mask[c] = m_c[c];
         continue;  // the improving cell equals the new maximum: neither X-drop nor the early exit can apply
       }
       if (!m_x || !m_alive) {  // reference :151 (band_max < max_score - x_drop), or our early exit
@@ -315,15 +324,15 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
     }
   }
 
-  // ---------------- argmax across lanes: first (j, i) attaining the maximum ----------------
-  const int gmax = wave_max(best);
-  if (gmax > 0) {
-    const int BIG = 0x0fffffff;  // -BIG must stay above the scan identity NEG
-    const int gj = wave_min(best == gmax ? best_j : BIG);
-    const int gi = wave_min((best == gmax && best_j == gj) ? best_i : BIG);
-    res.score = gmax;
-    res.xend = gi;
-    res.yend = gj;
+  // ---------------- first (j, i) attaining the maximum ----------------
+  if (run_max > 0) {
+    int bmin = 64 * CPL;
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+      if (best_mask[c]) bmin = min(bmin, (int)__builtin_ctzll(best_mask[c]) * CPL + c);
+    res.score = run_max;
+    res.xend = best_top + bmin;
+    res.yend = best_j;
   }
   return res;
 }
