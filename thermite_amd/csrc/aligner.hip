@@ -84,8 +84,6 @@ static int get_dev_copy(thm_aligner* a) {
     v.n = ix->n;
     v.n_refs = (uint32_t)ix->refs.size();
     v.n_txs = (uint32_t)ix->txs.size();
-    v.exon_root = ix->exon_root;
-    v.gene_root = ix->gene_root;
     v.kt = ix->kt;
     v.pad_ = 0;
     ix->dev[a->device] = d;

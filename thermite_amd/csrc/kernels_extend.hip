@@ -11,7 +11,7 @@
 //     lift_tx_to_gx         src/txome.rs:110-160
 //     Index::idx_to_ref     src/index.rs:287-290
 //     Index::seq_slice      src/index.rs:304-323     (a plain slice of the text: both strands are stored)
-//     IntervalTree::find    bio 0.37.1, replayed on the flattened AVL (same visit order)
+//     IntervalTree::find    bio 0.37.1, answered from the interval grids in the same yield order
 //
 // The hits of one read are processed strictly in the reference's order because
 // band_width / x_drop / max_aln_score are loop-carried (src/aligner.rs:143-175).
@@ -32,10 +32,6 @@ namespace dev {
 constexpr int MAX_YCLIPS = 64;
 enum : int { FAULT_OPS_POOL = 1, FAULT_INTERNAL = 2, FAULT_CONTRACT = 4 };
 
-__device__ __forceinline__ uint8_t sanitize_base_e(uint8_t c) {
-  if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
-  return (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') ? c : (uint8_t)0;
-}
 __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
   return ((unsigned long long)(unsigned)bcast_first((int)(v >> 32)) << 32) | (unsigned)bcast_first((int)(v & 0xffffffffu));
 }
@@ -80,7 +76,6 @@ struct Wctx {
   uint8_t* pc;
   int* mk_k;      // intron markers of the alignment being emitted: op index they precede ...
   uint32_t* ycl;  // ... and their lengths
-  int* stack;     // interval-tree traversal stack
   int L, opcap, wcap;
   unsigned cells, cols, calls, winbytes;
   int fault;
@@ -453,7 +448,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   const uint32_t ycols = p.max_read_len + p.max_bw + 2u;
   const uint32_t trb = (ycols + 1u) * CPL * 16u;
   const uint32_t opcap = (2u * p.max_read_len + 2u * p.max_bw + 31u) & ~15u;
-  const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * MAX_YCLIPS + 256u;
+  const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * MAX_YCLIPS;
   uint8_t* base = smem + (size_t)wave * per_wave;
   Wctx c;
   c.rd = base;
@@ -465,7 +460,6 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   c.pc = c.pb + opcap;
   c.mk_k = (int*)(c.pc + opcap);
   c.ycl = (uint32_t*)(c.mk_k + MAX_YCLIPS);
-  c.stack = (int*)(c.ycl + MAX_YCLIPS);
   c.opcap = (int)opcap;
   c.wcap = (int)wcap;
   c.cells = c.cols = c.calls = c.winbytes = 0;
@@ -541,6 +535,16 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
           const int hr = __builtin_amdgcn_readlane((int)my_sa, bcast_first((int)t));
           // ================= align_seed_hit (src/aligner.rs:198-314) =================
           const int bw = band_width, xd = x_drop;
+          // The genome window is requested before the contig lookup so that the two memory
+          // latencies overlap; it is loaded unclamped (the text is padded) and clamped to the
+          // contig logically below (:212-215).
+          const int gw_a = max(hr - (L + bw), 0);
+          const int gw_b = min(hr + len + L + bw, (int)ix.n);
+          const unsigned gw_mis = (unsigned)((uintptr_t)(ix.text + gw_a) & 15u);
+          const int gw_n = (gw_b - gw_a) + (int)gw_mis;
+          const uint4* gw_src = (const uint4*)(ix.text + gw_a - gw_mis);
+          uint4 gw_v = make_uint4(0, 0, 0, 0);
+          if (gw_n <= c.wcap && lane * 16 < gw_n) gw_v = gw_src[lane];
           const RefInfo ref = idx_to_ref(ix, (uint32_t)hr);
           const uint32_t qs = (uint32_t)hr, qe = (uint32_t)(hr + len);  // the seed on the concatenated text
 
@@ -568,7 +572,18 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
               const int rs = (int)ref.start;
               const int seq_start = max((hr > L + bw) ? hr - (L + bw) : 0, rs);
               const int seq_end = min(hr + len + L + bw, (int)ref.end - 1);
-              win0 = stage_window(c, c.wing, ix.text, seq_start, seq_end);
+              if (gw_n > c.wcap) {
+                c.fault |= FAULT_INTERNAL;
+              } else {
+                uint4* wdst = (uint4*)c.wing;
+                if (lane * 16 < gw_n) wdst[lane] = gw_v;
+#pragma unroll 1
+                for (int t2 = lane + 64; t2 * 16 < gw_n; t2 += 64) wdst[t2] = gw_src[t2];
+              }
+              c.winbytes += (unsigned)(seq_end - seq_start);
+              wfence();
+              PROF_MARK(c, PS_STAGE);
+              win0 = gw_a - (int)gw_mis;
               lo_abs = seq_start;
               hi_abs = seq_end;
               t_r = hr;
@@ -1048,7 +1063,7 @@ size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
   const uint32_t ycols = max_read_len + max_bw + 2u;
   const uint32_t trb = (ycols + 1u) * cpl * 16u;
   const uint32_t opcap = (2u * max_read_len + 2u * max_bw + 31u) & ~15u;
-  const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * dev::MAX_YCLIPS + 256u;
+  const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * dev::MAX_YCLIPS;
   return 4 * (size_t)per_wave;
 }
 

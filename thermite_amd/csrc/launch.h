@@ -113,7 +113,6 @@ struct ExtendParams {
   int* fault;  // bit 0: op pool overflow, bit 1: internal inconsistency, bit 2: out-of-contract (lift failure)
   uint32_t max_read_len;
   uint32_t max_bw;
-  uint32_t max_cols;
   unsigned long long* prof;  // 16 slots of shader clocks per section (THM_PROF builds), else unused
 };
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
@@ -128,7 +127,6 @@ struct CompactParams {
   const uint32_t* read_n_alns;
   const uint64_t* read_aln_off;  // exclusive scan of read_n_alns (as u64), [n_reads+1]
   const uint64_t* read_ops_off;  // exclusive scan of read_op_bytes, [n_reads+1]
-  uint32_t xlen_unused;
   const uint64_t* read_offsets;  // read lengths
   thm_aln* alns;
   uint8_t* ops;

@@ -146,7 +146,6 @@ int enqueue_run(thm_aligner* a) {
   ep.fault = a->d_fault.as<int>() + 1;
   ep.max_read_len = a->max_read_len;
   ep.max_bw = bw_max;
-  ep.max_cols = a->max_read_len + bw_max + 2;
   ep.prof = a->d_counters.as<unsigned long long>() + 2 * THM_N_COUNTERS;
   HIPCHK(a, launch_extend(ep, cpl, blocks_for(a, n, lds), s));
   HIPCHK(a, hipEventRecord(a->ev[3], s));
@@ -165,7 +164,6 @@ int enqueue_run(thm_aligner* a) {
   cp.read_n_alns = a->e_nalns.as<uint32_t>();
   cp.read_aln_off = a->e_aln_off.as<uint64_t>();
   cp.read_ops_off = a->e_ops_off.as<uint64_t>();
-  cp.xlen_unused = 0;
   cp.read_offsets = a->r_offsets.as<uint64_t>();
   cp.alns = a->o_alns.as<thm_aln>();
   cp.ops = a->o_ops.as<uint8_t>();

@@ -191,8 +191,12 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
       const int xv = (int)xs[min(max(b - 1, 0), xlen - 1) * dx];
       xc[c] = (b >= 1 && b < rows1) ? xv : 256;
     }
+    // the y character of the next column is fetched one column ahead, so that the LDS
+    // latency is off the column-to-column critical path
+    int yc_next = (int)ys[0];
     for (int j = 1; j <= p1_end; j++) {
-      const int yc = (int)ys[(j - 1) * dy];
+      const int yc = yc_next;
+      yc_next = (int)ys[min(j, ylen - 1) * dy];
       int d[CPL], Cn[CPL], key[CPL];
       const int d_in = wave_shr1(Dv[CPL - 1], MIN_SCORE);  // D[b-1] of the previous column for register 0
       int lane_tot = NEG;
@@ -252,7 +256,12 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
   }
 
   // ---------------- phase 2: band slides down (reference :116-154) ----------------
-  if (!finished) {
+  if (!finished && bw + 1 <= ylen) {
+    // x / y characters of the next column are fetched one column ahead (see phase 1)
+    int yc_next = (int)ys[bw * dy];
+    int xv_next[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) xv_next[c] = (int)xs[(min(1 + lane * CPL + c, xlen) - 1) * dx];
     for (int j = bw + 1; j <= ylen; j++) {
       const int top = j - bw;
       res.cols += 1;
@@ -262,7 +271,8 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
       }
       res.jmax = j;
       const int rows_end = min(top + w, xlen + 1);  // exclusive row bound
-      const int yc = (int)ys[(j - 1) * dy];
+      const int yc = yc_next;
+      yc_next = (int)ys[min(j, ylen - 1) * dy];
       int d[CPL], Cn[CPL], key[CPL], xc[CPL], base[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; c++) base[c] = max(Cv[c] + ge, Dv[c] + ge + go);
@@ -273,7 +283,8 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         const int b = lane * CPL + c;
         const int i = top + b;
         const bool valid = (b < w) && (i < rows_end);
-        const int xv = (int)xs[(min(i, xlen) - 1) * dx];
+        const int xv = xv_next[c];
+        xv_next[c] = (int)xs[(min(i + 1, xlen) - 1) * dx];
         xc[c] = valid ? xv : 256;
         const int cnext = (c == CPL - 1) ? c_in : base[c + 1];
         Cn[c] = (b >= w - 1) ? MIN_SCORE : cnext;

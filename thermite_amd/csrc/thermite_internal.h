@@ -21,7 +21,8 @@ constexpr int32_t MISMATCH_SCORE = -1;
 constexpr int32_t MIN_SCORE = -858993459;
 
 // ---- flattened interval tree (same shape and visit order as bio's AVL
-// IntervalTree built by the reference, src/index.rs:135,182-183,208-213) ----
+// IntervalTree built by the reference, src/index.rs:135,182-183,208-213); host
+// side only: the device uses the interval grids derived from it ----
 struct TreeNode {
   uint64_t start, end, max;
   uint32_t value;
@@ -64,7 +65,6 @@ struct DeviceIndex {
   const GridEntry* gene_grid;
   uint64_t n;
   uint32_t n_refs, n_txs;
-  int32_t exon_root, gene_root;
   uint32_t kt;
   uint32_t pad_;
 };
