@@ -141,3 +141,24 @@ def test_split_api_matches_one_shot(chrm):
     t = a.timings()
     assert t["total"] > 0 and t["extend"] > 0
     a.close()
+
+
+@pytest.mark.parametrize("opts", [
+    dict(min_seed_len=8, min_aln_score_percent=0.5, min_aln_score=20, multimap_score_range=0, intron_mode=True),
+    dict(min_seed_len=25, min_aln_score_percent=0.8, min_aln_score=30, multimap_score_range=2, intron_mode=False),
+    dict(min_seed_len=12, min_aln_score_percent=0.0, min_aln_score=0, multimap_score_range=3, intron_mode=True),
+])
+def test_option_sweep_with_dirty_reads(syn, opts):
+    """seed length below the k-mer table width (whole-range search path), score thresholds, multimap
+    ranges; reads with N, lower case and bytes outside the alphabet"""
+    rng = np.random.default_rng(5)
+    bases, off, _ = synth.simulate_reads(syn.t, 4000, 75, sub_rate=0.02, indel_rate=0.005, intronic_frac=0.3, stream=21)
+    b = bases.copy()
+    m = rng.random(len(b)) < 0.003
+    b[m] = ord("N")
+    m = rng.random(len(b)) < 0.0005
+    b[m] = ord("R")
+    lower = rng.random(len(b)) < 0.3
+    b[lower] = np.where((b[lower] >= 65) & (b[lower] <= 90), b[lower] + 32, b[lower])
+    check_smems(syn, b, off, opts["min_seed_len"])
+    check_align(syn, b, off, opts)

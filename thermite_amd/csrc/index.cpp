@@ -15,6 +15,7 @@
 // Pure host C++ (no HIP); device upload lives in aligner.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -173,6 +174,10 @@ void build_lut(thm_index* ix) {
   uint32_t kt = 1;
   // about one suffix per occupied bucket: 4^kt <= 4n, at most 14 (2 GiB of 8-byte entries)
   while (kt < 14 && (1ull << (2 * (kt + 1))) <= 4 * n) kt++;
+  if (const char* e = getenv("THM_KT")) {  // tuning knob
+    const int v = atoi(e);
+    if (v >= 1 && v <= 15) kt = (uint32_t)v;
+  }
   ix->kt = kt;
   const uint64_t nk = 1ull << (2 * kt);
   ix->lut.assign(nk, LutEntry{0, 0});
