@@ -84,6 +84,7 @@ struct Wctx {
 #ifdef THM_PROF
   unsigned long long prof_last;
   unsigned long long prof_acc[10];
+  unsigned long long prof_cols[3];
 #endif
 };
 
@@ -241,6 +242,14 @@ __device__ Path extend_lr(Wctx& c, const uint8_t* win, int win0, int lo_abs, int
   c.cells += R.cells + Lt.cells;
   c.cols += R.cols + Lt.cols;
   c.calls += 2;
+#ifdef THM_PROF
+  {  // how much of the DP runs on at most 32 band slots (two such problems could share a wave)
+    const bool nr_ = min(2 * bw + 1, xr + 1) <= 32, nl_ = min(2 * bw + 1, xl + 1) <= 32;
+    c.prof_cols[0] += R.cols + Lt.cols;
+    c.prof_cols[1] += (nr_ ? R.cols : 0) + (nl_ ? Lt.cols : 0);
+    c.prof_cols[2] += (nr_ && nl_) ? min(R.cols, Lt.cols) : 0;
+  }
+#endif
   if (nr < 0 || nl < 0 || nl + len + nr > c.opcap) {
     c.fault |= FAULT_INTERNAL;
     nl = 0;
@@ -468,6 +477,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   c.pool_left = 0;
 #ifdef THM_PROF
   for (int t = 0; t < 10; t++) c.prof_acc[t] = 0;
+  for (int t = 0; t < 3; t++) c.prof_cols[t] = 0;
   c.prof_last = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -980,7 +990,10 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
     for (int o = 32; o > 0; o >>= 1) k_type[t] += __shfl_xor(k_type[t], o);
 #ifdef THM_PROF
   if (lane == 0 && p.prof)
-    for (int t = 0; t < 10; t++) atomicAdd(&p.prof[t], c.prof_acc[t]);
+    {
+      for (int t = 0; t < 10; t++) atomicAdd(&p.prof[t], c.prof_acc[t]);
+      for (int t = 0; t < 3; t++) atomicAdd(&p.prof[10 + t], c.prof_cols[t]);
+    }
 #endif
   if (lane == 0) {
     if (c.fault) atomicOr(p.fault, c.fault);

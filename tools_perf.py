@@ -37,5 +37,6 @@ for name, opts in (("ci", capi.CI_OPTS), ("default", capi.DEFAULT_OPTS)):
     if pr.sum() > 0:
         names = ["setup", "stage", "dp", "traceback", "tree", "txprep", "lift", "emit", "final", "other"]
         tot = float(pr[:10].sum())
+        print("         DP columns: total %d, on <=32 slots %.1f%%, pairable (min of L/R when both <=32) %.1f%%" % (pr[10], 100.0 * pr[11] / max(pr[10], 1), 100.0 * pr[12] / max(pr[10], 1)), flush=True)
         print("         extend sections: " + " ".join("%s=%.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(names, pr[:10])), flush=True)
     a.close()
