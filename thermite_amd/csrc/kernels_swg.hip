@@ -25,11 +25,18 @@ __global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
   uint8_t* opsb = (uint8_t*)trace + tr_bytes;
 
   unsigned long long n_cells = 0, n_cols = 0, n_calls = 0;
+  constexpr unsigned QCHUNK = 8;  // problems per queue atomic (a single hot word serves ~88 M atomics/s)
+  unsigned q_next = 0, q_end = 0;
   for (;;) {
-    unsigned idx = 0;
-    if (lane == 0) idx = atomicAdd(p.queue, 1u);
-    idx = (unsigned)bcast_first((int)idx);
-    if (idx >= p.n) break;
+    if (q_next == q_end) {
+      unsigned g = 0;
+      if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
+      g = (unsigned)bcast_first((int)g);
+      if (g >= p.n) break;
+      q_next = g;
+      q_end = (unsigned)min((uint64_t)g + QCHUNK, p.n);
+    }
+    const unsigned idx = q_next++;
     const uint64_t x0 = p.xo[idx], y0 = p.yo[idx];
     const int xlen = (int)(p.xo[idx + 1] - x0);
     const int ylen_full = (int)(p.yo[idx + 1] - y0);
