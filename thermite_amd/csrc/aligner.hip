@@ -274,7 +274,12 @@ int32_t thm_swg_extend_batch(thm_aligner* a, const uint8_t* x_bases, const uint6
   p.queue = a->d_queue.as<unsigned int>();
   p.fault = a->d_fault.as<int>();
   p.n = n;
-  HIPCHK(a, launch_swg_batch(p, cpl, grid_blocks(a, n, 4, 4), s));
+  static const int bpc = [] {  // tuning knob: resident workgroups per CU
+    const char* e = getenv("THM_SWG_BPC");
+    const int v = e ? atoi(e) : 4;
+    return (v >= 1 && v <= 8) ? v : 4;
+  }();
+  HIPCHK(a, launch_swg_batch(p, cpl, grid_blocks(a, n, 4, bpc), s));
   std::vector<thm_swg_aln> raw(n);
   std::vector<uint8_t> pool_h(pool);
   int fault = 0;

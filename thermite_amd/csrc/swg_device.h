@@ -181,46 +181,49 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
   unsigned long long* tr = trace + (size_t)CPL * 2;  // column 1
 
   // ---------------- phase 1: band rows 0..w-1 (reference :75-113) ----------------
+  // Per-lane constants: slot index b, R offset go + b*ge, and -b*ge for the scan key.
   const int p1_end = min(bw, ylen);
   const int rows1 = min(w, xlen + 1);
   {
     int xc[CPL];
+    bool valid[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
       const int b = lane * CPL + c;
       const int xv = (int)xs[min(max(b - 1, 0), xlen - 1) * dx];
-      xc[c] = (b >= 1 && b < rows1) ? xv : 256;
+      valid[c] = b < rows1;
+      xc[c] = (b >= 1 && valid[c]) ? xv : 256;
     }
     // the y character of the next column is fetched one column ahead, so that the LDS
     // latency is off the column-to-column critical path
-    int yc_next = (int)ys[0];
+    const uint8_t* yp = ys;
+    int yc_next = (int)*yp;
     for (int j = 1; j <= p1_end; j++) {
       const int yc = yc_next;
-      yc_next = (int)ys[min(j, ylen - 1) * dy];
+      yp += dy;
+      yc_next = (int)*yp;  // one past the last column at most: still inside the staged window / LDS
       int d[CPL], Cn[CPL], key[CPL];
       const int d_in = wave_shr1(Dv[CPL - 1], MIN_SCORE);  // D[b-1] of the previous column for register 0
       int lane_tot = NEG;
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
-        const bool valid = b < rows1;
-        Cn[c] = max(Cv[c] + ge, Dv[c] + ge + go);
+        Cn[c] = max(Cv[c], Dv[c] + go) + ge;
         const int dprev = (c == 0) ? d_in : Dv[c - 1];
         d[c] = (b == 0) ? MIN_SCORE : dprev + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);
         const int dp = max(d[c], Cn[c]);
-        key[c] = valid ? dp - b * ge : NEG;
+        key[c] = valid[c] ? dp - b * ge : NEG;
         lane_tot = max(lane_tot, key[c]);
       }
       int run = wave_excl_max_scan_fast(lane_tot);
       unsigned long long m_imp = 0, m_alive = 0, m_c[CPL];
+      const int alive_floor = run_max - xlen;  // D + (xlen - i) > run_max  <=>  D - i > run_max - xlen
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
-        const bool valid = b < rows1;
-        const int R = run + go + b * ge;
+        const int R = run + (go + b * ge);
         run = max(run, key[c]);
-        const int dp = max(d[c], Cn[c]);
-        const int Dn = max(dp, R);
+        const int Dn = max(max(d[c], Cn[c]), R);
         // direction bits (Match 0, Subst 1, Del 2, Ins 3; priority diag > Del > Ins, reference :226-240)
         const unsigned long long hi = __ballot(Dn != d[c]);
         const unsigned long long lo = (~hi & ~__ballot(xc[c] == yc)) | (hi & __ballot(Dn != Cn[c]));
@@ -228,26 +231,28 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
           tr[c * 2 + 0] = lo;
           tr[c * 2 + 1] = hi;
         }
-        m_c[c] = __ballot(valid && Dn > run_max);
+        m_c[c] = __ballot(valid[c] && Dn > run_max);
         m_imp |= m_c[c];
-        m_alive |= __ballot(valid && (Dn + (xlen - b) > run_max));
-        Dv[c] = valid ? Dn : Dv[c];
-        Cv[c] = valid ? Cn[c] : Cv[c];
+        m_alive |= __ballot(valid[c] && (Dn - b > alive_floor));
+        Dv[c] = valid[c] ? Dn : Dv[c];
+        Cv[c] = valid[c] ? Cn[c] : Cv[c];
       }
       tr += CPL * 2;
       res.cells += (unsigned)rows1;
       res.cols += 1;
-      if (m_imp) {
-        run_max += MATCH_SCORE;
+      res.jmax = j;
+      const bool imp = m_imp != 0ull;
+      if (imp) {
         best_j = j;
         best_top = 0;
 #pragma unroll
         for (int c = 0; c < CPL; c++) best_mask[c] = m_c[c];
       }
+      run_max = bcast_first(run_max + (imp ? MATCH_SCORE : 0));
       // reference :110: with x_drop >= band_width the X-drop test cannot fire in
-      // phase 1; the early exit is ours (see above)
-      res.jmax = j;
-      if (!m_alive) {  // (an improving lane is alive by construction)
+      // phase 1; the early exit is ours (see above).
+      // (An improving lane is alive by construction.)
+      if (m_alive == 0ull) {
         finished = true;
         res.broke = true;
         break;
@@ -257,11 +262,21 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
 
   // ---------------- phase 2: band slides down (reference :116-154) ----------------
   if (!finished && bw + 1 <= ylen) {
-    // x / y characters of the next column are fetched one column ahead (see phase 1)
-    int yc_next = (int)ys[bw * dy];
+    // x / y characters of the next column are fetched one column ahead (see phase 1);
+    // per-lane pointers advance by one character per column.  Reads past the end of x
+    // land in other LDS bytes (or return 0 out of range) and are masked by `valid`.
+    const uint8_t* yp = ys + bw * dy;
+    int yc_next = (int)*yp;
+    const uint8_t* xp[CPL];
     int xv_next[CPL];
+    bool last_slot[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; c++) xv_next[c] = (int)xs[(min(1 + lane * CPL + c, xlen) - 1) * dx];
+    for (int c = 0; c < CPL; c++) {
+      const int b = lane * CPL + c;
+      xp[c] = xs + b * dx;  // x[i-1] with i = top + b, top = 1
+      xv_next[c] = (int)*xp[c];
+      last_slot[c] = b >= w - 1;
+    }
     for (int j = bw + 1; j <= ylen; j++) {
       const int top = j - bw;
       res.cols += 1;
@@ -270,65 +285,66 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         break;
       }
       res.jmax = j;
-      const int rows_end = min(top + w, xlen + 1);  // exclusive row bound
+      const int nvalid = min(w, xlen + 1 - top);  // slots b < nvalid hold a cell
       const int yc = yc_next;
-      yc_next = (int)ys[min(j, ylen - 1) * dy];
+      yp += dy;
+      yc_next = (int)*yp;
       int d[CPL], Cn[CPL], key[CPL], xc[CPL], base[CPL];
+      bool valid[CPL];
 #pragma unroll
-      for (int c = 0; c < CPL; c++) base[c] = max(Cv[c] + ge, Dv[c] + ge + go);
+      for (int c = 0; c < CPL; c++) base[c] = max(Cv[c], Dv[c] + go) + ge;
       const int c_in = wave_shl1(base[0], MIN_SCORE);  // slot b+1 of the previous column for the last register
       int lane_tot = NEG;
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
-        const int i = top + b;
-        const bool valid = (b < w) && (i < rows_end);
-        const int xv = xv_next[c];
-        xv_next[c] = (int)xs[(min(i + 1, xlen) - 1) * dx];
-        xc[c] = valid ? xv : 256;
+        valid[c] = b < nvalid;
+        xc[c] = valid[c] ? xv_next[c] : 256;
+        xp[c] += dx;
+        xv_next[c] = (int)*xp[c];
         const int cnext = (c == CPL - 1) ? c_in : base[c + 1];
-        Cn[c] = (b >= w - 1) ? MIN_SCORE : cnext;
+        Cn[c] = last_slot[c] ? MIN_SCORE : cnext;
         d[c] = Dv[c] + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);
         const int dp = max(d[c], Cn[c]);
-        key[c] = valid ? dp - b * ge : NEG;
+        key[c] = valid[c] ? dp - b * ge : NEG;
         lane_tot = max(lane_tot, key[c]);
       }
       int run = wave_excl_max_scan_fast(lane_tot);
       unsigned long long m_imp = 0, m_alive = 0, m_x = 0, m_c[CPL];
-      const int xfloor = run_max - xd;  // tested against the updated run_max below
+      const int xfloor = run_max - xd;               // X-drop survivors: D >= max_score - x_drop
+      const int alive_floor = run_max - xlen + top;  // D + (xlen - i) > run_max  <=>  D - b > run_max - xlen + top
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
-        const int i = top + b;
-        const bool valid = (b < w) && (i < rows_end);
-        const int R = run + go + b * ge;
+        const int R = run + (go + b * ge);
         run = max(run, key[c]);
-        const int dp = max(d[c], Cn[c]);
-        const int Dn = max(dp, R);
+        const int Dn = max(max(d[c], Cn[c]), R);
         const unsigned long long hi = __ballot(Dn != d[c]);
         const unsigned long long lo = (~hi & ~__ballot(xc[c] == yc)) | (hi & __ballot(Dn != Cn[c]));
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
           tr[c * 2 + 1] = hi;
         }
-        m_c[c] = __ballot(valid && Dn > run_max);
+        m_c[c] = __ballot(valid[c] && Dn > run_max);
         m_imp |= m_c[c];
-        m_x |= __ballot(valid && Dn >= xfloor);  // X-drop survivors (only consulted when nothing improved)
-        m_alive |= __ballot(valid && (Dn + (xlen - i) > run_max));
-        Dv[c] = valid ? Dn : Dv[c];
+        m_x |= __ballot(valid[c] && Dn >= xfloor);
+        m_alive |= __ballot(valid[c] && (Dn - b > alive_floor));
+        Dv[c] = valid[c] ? Dn : Dv[c];
         Cv[c] = Cn[c];
       }
       tr += CPL * 2;
-      res.cells += (unsigned)(rows_end - top);
-      if (m_imp) {
-        run_max += MATCH_SCORE;
+      res.cells += (unsigned)nvalid;
+      const bool imp = m_imp != 0ull;
+      if (imp) {
         best_j = j;
         best_top = top;
 #pragma unroll
         for (int c = 0; c < CPL; c++) best_mask[c] = m_c[c];
-        continue;  // the improving cell equals the new maximum: neither X-drop nor the early exit can apply
       }
-      if (!m_x || !m_alive) {  // reference :151 (band_max < max_score - x_drop), or our early exit
+      run_max = bcast_first(run_max + (imp ? MATCH_SCORE : 0));
+      // stop: reference :151 (band_max < max_score - x_drop) or our early exit; an improving
+      // column equals the new maximum, so neither applies to it
+      if (!imp && (m_x == 0ull || m_alive == 0ull)) {
         res.broke = true;
         break;
       }
