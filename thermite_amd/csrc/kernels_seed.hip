@@ -231,19 +231,28 @@ __global__ void sanitize_kernel(const uint8_t* in, uint8_t* out, uint64_t n, uin
     out[i] = 0;
 }
 
-// matching statistics: one thread per (read, position)
+// Matching statistics, one thread per (read, position), in two launches.
+// FIRST: position 0 of every read.  REST: positions >= 1, skipped when the match
+// from position 0 already reaches the end of the read: ends are non-decreasing in
+// the start position, so no later start can open a new SMEM (end[i] > end[i-1] is
+// impossible once end == L) -- the common case for error-free reads, which then
+// cost one probe instead of L-k+1.
+template <bool FIRST>
 __global__ __launch_bounds__(256) void seed_probe_kernel(SeedParams p) {
-  const uint64_t item = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint32_t P = p.pos_per_read;
-  const uint64_t read = item / P;
+  const uint64_t read = FIRST ? tid : tid / P;
   if (read >= p.reads.n_reads) return;
-  const int pos = (int)(item - read * P);
+  const int pos = FIRST ? 0 : (int)(tid - read * P);
+  const uint64_t item = read * P + (uint64_t)pos;
+  if (!FIRST && pos == 0) return;
   const uint64_t r0 = p.reads.offsets[read];
   const int L = (int)(p.reads.offsets[read + 1] - r0);
   const int k = (int)p.min_seed_len;
   int d = 0;
   uint32_t lo = 0, hi = 0;
-  if (pos + k <= L) ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
+  const bool covered = !FIRST && L > 0 && (int)p.ms_end[read * P] == L;
+  if (!covered && pos + k <= L) ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
   p.ms_end[item] = (uint16_t)((d >= k) ? pos + d : 0);
   p.ms_lo[item] = lo;
   p.ms_hi[item] = hi;
@@ -430,8 +439,11 @@ hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t
 hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s) {
   const uint64_t items = p.reads.n_reads * (uint64_t)p.pos_per_read;
   if (items) {
-    hipLaunchKernelGGL(dev::seed_probe_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dev::seed_probe_kernel<true>, dim3((unsigned)((p.reads.n_reads + 255) / 256)), dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dev::seed_probe_kernel<false>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   const size_t lds = seed_lds_bytes(p.max_read_len);

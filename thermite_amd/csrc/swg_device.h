@@ -105,6 +105,21 @@ struct SwgResult {
 // inside an asm statement).
 __device__ __forceinline__ int wave_excl_max_scan_fast(int v) {
   int r = NEG;
+#if defined(THM_EXP_NOSCAN)
+  return wave_shr1(v, NEG);
+#elif defined(THM_EXP_NONOP)
+  asm("s_nop 1\n\t"
+      "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(r)
+      : "v"(v));
+  return r;
+#endif
   asm("s_nop 1\n\t"
       "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\t"
@@ -227,10 +242,14 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         // direction bits (Match 0, Subst 1, Del 2, Ins 3; priority diag > Del > Ins, reference :226-240)
         const unsigned long long hi = __ballot(Dn != d[c]);
         const unsigned long long lo = (~hi & ~__ballot(xc[c] == yc)) | (hi & __ballot(Dn != Cn[c]));
+#ifndef THM_EXP_NOTRACE
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
           tr[c * 2 + 1] = hi;
         }
+#else
+        if (lo == 0x123456789ull && hi == 0x3ull && lane == 0) tr[0] = lo;
+#endif
         m_c[c] = __ballot(valid[c] && Dn > run_max);
         m_imp |= m_c[c];
         m_alive |= __ballot(valid[c] && (Dn - b > alive_floor));
@@ -321,10 +340,14 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         const int Dn = max(max(d[c], Cn[c]), R);
         const unsigned long long hi = __ballot(Dn != d[c]);
         const unsigned long long lo = (~hi & ~__ballot(xc[c] == yc)) | (hi & __ballot(Dn != Cn[c]));
+#ifndef THM_EXP_NOTRACE
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
           tr[c * 2 + 1] = hi;
         }
+#else
+        if (lo == 0x123456789ull && hi == 0x3ull && lane == 0) tr[0] = lo;
+#endif
         m_c[c] = __ballot(valid[c] && Dn > run_max);
         m_imp |= m_c[c];
         m_x |= __ballot(valid[c] && Dn >= xfloor);
