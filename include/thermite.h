@@ -252,6 +252,8 @@ const char* thm_last_error(const thm_aligner*); /* NULL-safe: global last error 
 int32_t thm_aligner_set_opts(thm_aligner*, const thm_align_opts*);
 /* the aligner's hipStream_t, as void* (for events / ExternalStream) */
 void* thm_aligner_stream(thm_aligner*);
+/* the index the aligner was created over (ThermiteAligner::index, src/wrapper.rs:22) */
+const thm_index* thm_aligner_index(const thm_aligner*);
 
 /* aligner::align_read (src/aligner.rs:123-190) for a batch.  `bases` holds the
  * reads back to back, read r = bases[offsets[r] .. offsets[r+1]).  Host

@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
+from oracle import aln_writer as ow  # noqa: E402
 from oracle import pyoracle as orc  # noqa: E402
 from thermite_amd import capi, refdata, synth  # noqa: E402
 
@@ -52,6 +53,12 @@ def main():
     g = dict(source="CPU oracle (restatement), reference data/test_query.fastq vs data/test_ref.{fasta,gtf}, -k3 --min-aln-score=0",
              opts=opts, reads=dump(t, names, bases, off, opts))
     json.dump(g, open(os.path.join(HERE, "test_query_alignments.json"), "w"), indent=1)
+    # the same run rendered by the restated writer (src/aln_writer.rs): what `thermite align -a` / PAF would print
+    names, seqs, quals = refdata.parse_fastq(os.path.join(DATA, "test_query.fastq"))
+    r = orc.Index(t).align_batch(bases, off, opts)
+    nb, sb, qb = [n.encode() for n in names], [bytes(x) for x in seqs], [bytes(q) for q in quals]
+    open(os.path.join(HERE, "test_query.sam"), "wb").write(ow.sam_header(t) + ow.format_batch(t, nb, sb, qb, r, "sam"))
+    open(os.path.join(HERE, "test_query.paf"), "wb").write(ow.format_batch(t, nb, sb, qb, r, "paf"))
     tm = refdata.load_reference(os.path.join(DATA, "GRCh38-2020-A-chrM.fasta"), os.path.join(DATA, "GRCh38-2020-A-chrM.gtf"))
     b, o, _ = synth.simulate_reads(tm, 200, 91, sub_rate=0.02, indel_rate=0.005, stream=42)
     g = dict(source="CPU oracle (restatement), 200 synthetic 91 bp reads (thermite_amd.synth, stream 42) vs chrM, -k20 -s0 --intron-mode",

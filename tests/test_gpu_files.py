@@ -1,0 +1,76 @@
+"""-m gpu: the whole-file driver (thm_align_files: FASTQ -> HIP path -> SAM / PAF) against the
+oracle's alignments rendered by the oracle's writer, byte for byte."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from oracle import aln_writer as ow
+from oracle import pyoracle as orc
+from thermite_amd import capi, refdata, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_test_query_files_match_goldens(data_dir, golden_dir, tmp_path):
+    """config 1 end to end from the files: data/test_ref.{fasta,gtf} + data/test_query.fastq, -k3 --min-aln-score=0"""
+    ix = capi.Index.from_files(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    a = capi.Aligner(ix, dict(capi.DEFAULT_OPTS, min_seed_len=3, min_aln_score=0))
+    for fmt, name in ((capi.FMT_SAM, "test_query.sam"), (capi.FMT_PAF, "test_query.paf")):
+        out = tmp_path / name
+        st = capi.align_files(a, [data_dir + "/test_query.fastq"], out, fmt, batch_reads=4, n_threads=2)
+        assert open(out, "rb").read() == open(os.path.join(golden_dir, name), "rb").read()
+        assert st["n_reads"] == 10 and st["n_batches"] == 3 and st["n_aligned_reads"] == 8
+    a.close()
+
+
+@pytest.mark.parametrize("opts_name", ["ci", "default"])
+def test_chrM_fastq_to_sam_matches_oracle(data_dir, tmp_path, opts_name):
+    opts = capi.CI_OPTS if opts_name == "ci" else capi.DEFAULT_OPTS
+    fa, gtf = data_dir + "/GRCh38-2020-A-chrM.fasta", data_dir + "/GRCh38-2020-A-chrM.gtf"
+    t = refdata.load_reference(fa, gtf)
+    n = 5000
+    bases, off, _ = synth.simulate_reads(t, n, 91, sub_rate=0.02, indel_rate=0.004, stream=11)
+    rng = np.random.default_rng(5)
+    seqs = [bytes(bases[int(off[i]): int(off[i + 1])]) for i in range(n)]
+    quals = [bytes(rng.integers(33, 74, len(s)).astype(np.uint8)) for s in seqs]
+    names = [("r%d 1:N:0" % i).encode() for i in range(n)]
+    # two input files (one gzip), as `thermite align idx a.fastq b.fastq.gz`
+    half = n // 2 + 17
+    p1, p2 = tmp_path / "a.fastq", tmp_path / "b.fastq.gz"
+    rec = lambda i: b"@" + names[i] + b"\n" + seqs[i] + b"\n+\n" + quals[i] + b"\n"
+    p1.write_bytes(b"".join(rec(i) for i in range(half)))
+    with gzip.open(p2, "wb") as f:
+        f.write(b"".join(rec(i) for i in range(half, n)))
+    res = orc.Index(t).align_batch(bases, off, opts, n_threads=8)
+    ix = capi.Index.from_files(fa, gtf)
+    idx_path = tmp_path / "chrM.thmidx"
+    ix.save(idx_path)
+    a = capi.Aligner(capi.Index.load(idx_path), opts)  # through the index container, like `thermite align <index>`
+    for fmt, key in ((capi.FMT_SAM, "sam"), (capi.FMT_PAF, "paf")):
+        out = tmp_path / ("out." + key)
+        st = capi.align_files(a, [p1, p2], out, fmt, batch_reads=777, n_threads=4)
+        want = (ow.sam_header(t) if key == "sam" else b"") + ow.format_batch(t, names, seqs, quals, res, key)
+        got = open(out, "rb").read()
+        assert got == want, key
+        assert st["n_reads"] == n and st["n_output_bytes"] == len(want)
+        assert st["n_aligned_reads"] == int(res.counters[1])
+    a.close()
+
+
+def test_align_files_reports_errors(data_dir, tmp_path):
+    ix = capi.Index.from_files(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    a = capi.Aligner(ix, capi.DEFAULT_OPTS)
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.align_files(a, [tmp_path / "missing.fastq"], tmp_path / "o.sam", capi.FMT_SAM)
+    assert e.value.code == capi.ERR_IO
+    bad = tmp_path / "bad.fastq"
+    bad.write_bytes(b"@r\nACGT\n+\n!!\n")
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.align_files(a, [bad], tmp_path / "o.sam", capi.FMT_SAM)
+    assert e.value.code == capi.ERR_FORMAT
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.align_files(a, [data_dir + "/test_query.fastq"], tmp_path / "o.bam", capi.FMT_BAM)
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    a.close()

@@ -1,0 +1,261 @@
+"""Host-side I/O either side of the hot path (include/thermite_io.h), on the CPU:
+reference ingestion vs the Python restatement (thermite_amd/refdata.py), the index
+container, the FASTQ batcher, and the SAM / PAF writer vs the oracle's restatement
+of src/aln_writer.rs (oracle/aln_writer.py) on alignments the CPU oracle produced.
+"""
+import ctypes
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import aln_writer as ow
+from oracle import pyoracle as orc
+from thermite_amd import capi, refdata, synth
+
+REFS = [("test_ref.fasta", "test_ref.gtf"), ("GRCh38-2020-A-chrM.fasta", "GRCh38-2020-A-chrM.gtf")]
+
+
+def _same(a, b):
+    return np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+
+
+def test_io_header_symbols_exported():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "thermite_io.h")).read()
+    declared = set(re.findall(r"\b(thm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.IO_ABI_SYMBOLS)
+    L = ctypes.CDLL(capi.SO_PATH)
+    for s in sorted(declared):
+        assert hasattr(L, s), "missing export: " + s
+
+
+@pytest.mark.parametrize("fa,gtf", REFS)
+def test_native_ingestion_matches_python_restatement(data_dir, fa, gtf):
+    ix = capi.Index.from_files(data_dir + "/" + fa, data_dir + "/" + gtf)
+    nt = ix.native_tables()
+    pt = refdata.load_reference(data_dir + "/" + fa, data_dir + "/" + gtf)
+    for k in pt:
+        assert _same(pt[k], nt[k]), k
+    # and the search structures are the ones the in-memory constructor builds
+    assert np.array_equal(ix.suffix_array(), capi.Index(pt).suffix_array())
+
+
+def test_ingestion_reads_gzip_and_rejects_bad_input(data_dir, tmp_path):
+    fa, gtf = data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf"
+    gz = tmp_path / "ref.fasta.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(open(fa, "rb").read())
+    a = capi.Index.from_files(gz, gtf).native_tables()
+    b = capi.Index.from_files(fa, gtf).native_tables()
+    assert all(_same(a[k], b[k]) for k in a)
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.Index.from_files(tmp_path / "missing.fasta", gtf)
+    assert e.value.code == capi.ERR_IO
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">c1\nACGTXACGT\n")
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.Index.from_files(bad, gtf)
+    assert e.value.code == capi.ERR_FORMAT
+    badgtf = tmp_path / "bad.gtf"
+    badgtf.write_text('some_ref\tx\texon\t1\t5\t.\t+\t.\tgene_id "g"; transcript_id "nope";\n')
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.Index.from_files(fa, badgtf)
+    assert e.value.code == capi.ERR_FORMAT
+
+
+@pytest.mark.parametrize("fa,gtf", REFS)
+def test_index_container_round_trip(data_dir, tmp_path, fa, gtf):
+    ix = capi.Index.from_files(data_dir + "/" + fa, data_dir + "/" + gtf)
+    p = tmp_path / "ref.thmidx"
+    ix.save(p)
+    ix2 = capi.Index.load(p)
+    a, b = ix.native_tables(), ix2.native_tables()
+    assert all(_same(a[k], b[k]) for k in a)
+    assert np.array_equal(ix.suffix_array(), ix2.suffix_array())
+    # corruption and truncation are detected, not loaded
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    (tmp_path / "corrupt.thmidx").write_bytes(raw)
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.Index.load(tmp_path / "corrupt.thmidx")
+    assert e.value.code == capi.ERR_FORMAT
+    (tmp_path / "short.thmidx").write_bytes(raw[: len(raw) - 7])
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.Index.load(tmp_path / "short.thmidx")
+    assert e.value.code == capi.ERR_FORMAT
+    (tmp_path / "other.thmidx").write_bytes(b"not an index at all" * 20)
+    with pytest.raises(capi.ThermiteError):
+        capi.Index.load(tmp_path / "other.thmidx")
+
+
+def _collect(reader, batch):
+    names, seqs, quals = [], [], []
+    while True:
+        b = reader.next_batch(batch)
+        if b is None:
+            break
+        for i in range(len(b["offsets"]) - 1):
+            s, e = int(b["offsets"][i]), int(b["offsets"][i + 1])
+            seqs.append(bytes(b["bases"][s:e]))
+            quals.append(None if b["quals"] is None else bytes(b["quals"][s:e]))
+            names.append(bytes(b["names"][int(b["name_off"][i]): int(b["name_off"][i + 1])]))
+    return names, seqs, quals
+
+
+@pytest.mark.parametrize("batch", [1, 3, 1000])
+def test_fastq_batcher(data_dir, tmp_path, batch):
+    path = data_dir + "/test_query.fastq"
+    names, seqs, quals = refdata.parse_fastq(path)
+    got = _collect(capi.FastqReader(path), batch)
+    assert got[0] == [n.encode() for n in names]
+    assert got[1] == [bytes(s) for s in seqs]
+    assert got[2] == [bytes(q) for q in quals]
+    gz = tmp_path / "q.fastq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(open(path, "rb").read().replace(b"\n", b"\r\n"))  # CRLF line ends are stripped too
+    assert _collect(capi.FastqReader(gz), batch) == got
+
+
+def test_fastq_batcher_edge_cases(tmp_path):
+    p = tmp_path / "e.fastq"
+    p.write_bytes(b"@empty read\n\n+\n\n@r2 extra words\nACGTN\n+r2\n!!!!#\n")
+    names, seqs, quals = _collect(capi.FastqReader(p), 10)
+    assert names == [b"empty read", b"r2 extra words"] and seqs == [b"", b"ACGTN"] and quals == [b"", b"!!!!#"]
+    fa = tmp_path / "q.fasta"
+    fa.write_bytes(b">a desc\nACG\nTTA\n>b\nGG\n")
+    names, seqs, quals = _collect(capi.FastqReader(fa), 10)
+    assert names == [b"a desc", b"b"] and seqs == [b"ACGTTA", b"GG"] and quals == [None, None]
+    for bad in (b"@r\nACGT\n+\n!!\n", b"@r\nACGT\nACGT\n!!!!\n", b"ACGT\n", b"@r\nACGT\n"):
+        q = tmp_path / "bad.fastq"
+        q.write_bytes(bad)
+        with pytest.raises(capi.ThermiteError) as e:
+            _collect(capi.FastqReader(q), 10)
+        assert e.value.code == capi.ERR_FORMAT
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.FastqReader(tmp_path / "nope.fastq")
+    assert e.value.code == capi.ERR_IO
+
+
+def test_multimapq_table():
+    """the table in the doc comment of multimapq, reference src/aln_writer.rs:327-331"""
+    assert [ow.multimapq(n) for n in (0, 1, 2, 3, 4, 5, 6, 100)] == [255, 255, 3, 2, 1, 0, 0, 0]
+
+
+def test_cigar_run_length_rules():
+    """to_noodles_cigar, reference src/aln_writer.rs:279-323"""
+    assert ow.to_cigar([]) == "*"
+    assert ow.to_cigar(["Match", "Subst", "Match", "Ins", "Ins", "Del", "Match", ("Xclip", 7)]) == "3M2I1D1M7S"
+    assert ow.to_cigar([("Xclip", 2), "Match", ("Yclip", 40), "Subst", "Subst"]) == "2S1M40N2M"
+    # equal neighbouring clips form one run that keeps the clip's own length; unequal ones do not merge
+    assert ow.to_cigar([("Yclip", 5), ("Yclip", 5), "Match"]) == "5N1M"
+    assert ow.to_cigar([("Yclip", 5), ("Yclip", 6), "Match"]) == "5N6N1M"
+
+
+def _batch(names, seqs, quals):
+    bases, off = refdata.pack_reads(seqs)
+    nb, noff = refdata.pack_reads([n if isinstance(n, bytes) else n.encode() for n in names])
+    qb, _ = refdata.pack_reads(quals)
+    return dict(bases=bases, offsets=off, quals=qb, names=nb, name_off=noff)
+
+
+def _check_writer(tables, names, seqs, quals, res):
+    ix = capi.Index(tables)
+    batch = _batch(names, seqs, quals)
+    sam = None
+    for fmt, key in ((capi.FMT_SAM, "sam"), (capi.FMT_PAF, "paf")):
+        want = ow.format_batch(tables, [n if isinstance(n, bytes) else n.encode() for n in names], seqs, quals, res, key)
+        for threads in (1, 3):
+            w = capi.Writer(ix, fmt, threads)
+            got = w.format_batch(batch, res)
+            assert got == want, (key, threads)
+            if fmt == capi.FMT_SAM:
+                assert w.header() == ow.sam_header(tables)
+                sam = want
+            else:
+                assert w.header() == b""
+    return sam
+
+
+def test_writer_on_reference_test_query(data_dir):
+    """config 1: data/test_query.fastq vs data/test_ref.*, flags of reference data/Makefile:21"""
+    t = refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    names, seqs, quals = refdata.parse_fastq(data_dir + "/test_query.fastq")
+    bases, off = refdata.pack_reads(seqs)
+    opts = dict(capi.DEFAULT_OPTS, min_seed_len=3, min_aln_score=0)
+    res = orc.Index(t).align_batch(bases, off, opts)
+    text = _check_writer(t, names, [bytes(s) for s in seqs], [bytes(q) for q in quals], res)
+    lines = text.split(b"\n")
+    assert any(b"\t4\t*\t0\t255\t*\t*\t0\t0\t" in ln for ln in lines)  # the read named "unmapped"
+    assert any(b"N" in ln.split(b"\t")[5] and b"RE:A:E" in ln for ln in lines if ln)  # spliced reads carry an N
+
+
+@pytest.mark.parametrize("opts", [capi.CI_OPTS, capi.DEFAULT_OPTS])
+def test_writer_on_chrM_reads(data_dir, opts):
+    t = refdata.load_reference(data_dir + "/GRCh38-2020-A-chrM.fasta", data_dir + "/GRCh38-2020-A-chrM.gtf")
+    bases, off, _ = synth.simulate_reads(t, 600, 91, sub_rate=0.02, indel_rate=0.004, stream=7)
+    seqs = [bytes(bases[int(off[i]): int(off[i + 1])]) for i in range(len(off) - 1)]
+    rng = np.random.default_rng(3)
+    quals = [bytes(rng.integers(33, 74, len(s)).astype(np.uint8)) for s in seqs]
+    names = ["read%d with a comment" % i if i % 3 else "read%d" % i for i in range(len(seqs))]
+    res = orc.Index(t).align_batch(bases, off, opts)
+    text = _check_writer(t, names, seqs, quals, res)
+    assert text.count(b"\n") >= 500
+
+
+def test_writer_on_constructed_records(data_dir):
+    """hand-made results: multimap counts 0..6, both strands, secondary flags, clip runs, an empty read"""
+    t = refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    op_lists = [["Match"] * 4, [("Xclip", 2), "Match", "Subst", ("Yclip", 4), "Match", "Del", "Ins", ("Xclip", 1)], []]
+    alns, ops, offsets = [], bytearray(), [0]
+    seqs, quals, names = [], [], []
+    for n in range(0, 7):
+        seqs.append(b"ACGTNacgtRY"[: 4 + n])
+        quals.append(bytes(range(40, 44 + n)))
+        names.append("q%d some comment" % n)
+        for j in range(n):
+            a = np.zeros(1, capi.ALN_DT)[0]
+            o = orc.encode_ops(op_lists[(n + j) % 3])
+            a["ops_off"], a["ops_len"] = len(ops), len(o)
+            ops += o
+            to = orc.encode_ops(op_lists[(n + j + 1) % 3])
+            a["tx_ops_off"], a["tx_ops_len"] = len(ops), len(to)
+            ops += to
+            a["ref_id"] = (n + j) % len(t["refs"])
+            a["strand"] = t["refs"][a["ref_id"]]["strand"]
+            a["primary"] = 1 if j == 0 else 0
+            a["aln_type"] = (n + j) % 3
+            a["tx_or_gene_idx"] = 0 if a["aln_type"] != 2 else 0xFFFFFFFF
+            a["score"], a["ystart"], a["yend"], a["ylen"] = 7 - j, 3 + j, 9 + j, 26
+            a["xstart"], a["xend"], a["xlen"], a["tx_ystart"] = j % 2, 4 + n, 4 + n, 11 * j
+            alns.append(a)
+        offsets.append(len(alns))
+    seqs.append(b"")
+    quals.append(b"")
+    names.append("empty")
+    offsets.append(len(alns))
+
+    class R:
+        pass
+
+    res = R()
+    res.n_reads = len(seqs)
+    res.offsets = np.array(offsets, "<u8")
+    res.alns = np.array(alns, capi.ALN_DT)
+    res.ops = np.frombuffer(bytes(ops), np.uint8).copy()
+    text = _check_writer(t, names, seqs, quals, res)
+    mapq = [ln.split(b"\t")[4] for ln in text.split(b"\n") if ln and not ln.startswith(b"q0") and not ln.startswith(b"empty")]
+    assert mapq[:1] == [b"255"] and mapq[1:3] == [b"3", b"3"] and mapq[-6:] == [b"0"] * 6
+
+
+def test_oracle_writer_reproduces_committed_sam_paf(data_dir, golden_dir):
+    """tests/golden/test_query.{sam,paf} (made by tests/golden/make_goldens.py) pin the restated writer"""
+    t = refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    names, seqs, quals = refdata.parse_fastq(data_dir + "/test_query.fastq")
+    bases, off = refdata.pack_reads(seqs)
+    res = orc.Index(t).align_batch(bases, off, dict(capi.DEFAULT_OPTS, min_seed_len=3, min_aln_score=0))
+    nb, sb, qb = [n.encode() for n in names], [bytes(s) for s in seqs], [bytes(q) for q in quals]
+    assert ow.sam_header(t) + ow.format_batch(t, nb, sb, qb, res, "sam") == open(golden_dir + "/test_query.sam", "rb").read()
+    assert ow.format_batch(t, nb, sb, qb, res, "paf") == open(golden_dir + "/test_query.paf", "rb").read()

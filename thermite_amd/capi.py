@@ -101,7 +101,17 @@ ABI_SYMBOLS = [
     "thm_aligner_set_opts", "thm_aligner_stream", "thm_align_batch", "thm_batch_upload", "thm_batch_run",
     "thm_batch_sync", "thm_batch_fetch", "thm_smems_batch", "thm_swg_extend_batch", "thm_counters_get",
     "thm_counters_reset", "thm_counters_device_ptr", "thm_timings_get", "thm_version", "thm_device_count",
+    "thm_aligner_index",
 ]
+# every symbol include/thermite_io.h declares
+IO_ABI_SYMBOLS = [
+    "thm_index_create_from_files", "thm_index_set_names", "thm_index_save", "thm_index_load", "thm_index_tables",
+    "thm_index_contig_name", "thm_index_tx_id", "thm_index_gene_id", "thm_index_gene_name", "thm_fastq_open",
+    "thm_fastq_next_batch", "thm_fastq_close", "thm_writer_create", "thm_writer_free", "thm_writer_header",
+    "thm_writer_format_batch", "thm_align_files",
+]
+ERR_IO, ERR_FORMAT = -8, -9
+FMT_PAF, FMT_SAM, FMT_BAM = 0, 1, 2
 
 _lib = None
 
@@ -156,6 +166,37 @@ def lib():
     L.thm_timings_get.argtypes = [vp, vp]
     L.thm_version.restype = C.c_char_p
     L.thm_device_count.restype = i32
+    L.thm_aligner_index.restype = vp
+    L.thm_aligner_index.argtypes = [vp]
+    # ---- include/thermite_io.h ----
+    cp = C.c_char_p
+    L.thm_index_create_from_files.restype = i32
+    L.thm_index_create_from_files.argtypes = [cp, cp, vp]
+    L.thm_index_set_names.restype = i32
+    L.thm_index_set_names.argtypes = [vp, vp, u32, vp, u32, vp, vp, u32]
+    L.thm_index_save.restype = i32
+    L.thm_index_save.argtypes = [vp, cp]
+    L.thm_index_load.restype = i32
+    L.thm_index_load.argtypes = [cp, vp]
+    L.thm_index_tables.restype = i32
+    L.thm_index_tables.argtypes = [vp, vp]
+    for f in ("thm_index_contig_name", "thm_index_tx_id", "thm_index_gene_id", "thm_index_gene_name"):
+        getattr(L, f).restype = cp
+        getattr(L, f).argtypes = [vp, u32]
+    L.thm_fastq_open.restype = i32
+    L.thm_fastq_open.argtypes = [cp, vp]
+    L.thm_fastq_next_batch.restype = i32
+    L.thm_fastq_next_batch.argtypes = [vp, u64, vp]
+    L.thm_fastq_close.argtypes = [vp]
+    L.thm_writer_create.restype = i32
+    L.thm_writer_create.argtypes = [vp, i32, u32, vp]
+    L.thm_writer_free.argtypes = [vp]
+    L.thm_writer_header.restype = i32
+    L.thm_writer_header.argtypes = [vp, vp]
+    L.thm_writer_format_batch.restype = i32
+    L.thm_writer_format_batch.argtypes = [vp, vp, vp, vp]
+    L.thm_align_files.restype = i32
+    L.thm_align_files.argtypes = [vp, vp, u32, cp, i32, u64, u32, vp]
     if hasattr(L, "thm_debug_prof_get"):
         L.thm_debug_prof_get.restype = i32
         L.thm_debug_prof_get.argtypes = [vp, vp, i32]
@@ -193,8 +234,100 @@ def build_suffix_array(text):
     return sa
 
 
+class TablesView(C.Structure):
+    _fields_ = [("n_text", C.c_uint64), ("text", C.c_void_p), ("n_refs", C.c_uint32), ("refs", C.c_void_p),
+                ("n_txs", C.c_uint32), ("txs", C.c_void_p), ("n_exons", C.c_uint64), ("exons", C.c_void_p),
+                ("n_tx_seq", C.c_uint64), ("tx_seq", C.c_void_p), ("n_genes", C.c_uint32), ("genes", C.c_void_p),
+                ("name_rank", C.c_void_p), ("n_contigs", C.c_uint32)]
+
+
+class ReadBatch(C.Structure):
+    """thm_read_batch"""
+
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("bases", C.c_void_p), ("offsets", C.c_void_p),
+                ("quals", C.c_void_p), ("names", C.c_void_p), ("name_off", C.c_void_p)]
+
+
+class Text(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_uint64)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_aligned_reads", C.c_uint64), ("n_records", C.c_uint64),
+                ("n_batches", C.c_uint64), ("n_output_bytes", C.c_uint64), ("parse_s", C.c_double),
+                ("gpu_s", C.c_double), ("format_s", C.c_double), ("write_s", C.c_double), ("wall_s", C.c_double)]
+
+
+def _last_error(h=None):
+    return (lib().thm_last_error(h) or b"").decode()
+
+
+def _cstr_array(strs):
+    arr = (C.c_char_p * len(strs))(*[s.encode() if isinstance(s, str) else bytes(s) for s in strs])
+    return arr
+
+
 class Index:
     """thm_index: the in-memory index (stands for reference Index, src/index.rs:39-44)."""
+
+    @classmethod
+    def _wrap(cls, h):
+        self = cls.__new__(cls)
+        self.h = h
+        self.tables = None
+        return self
+
+    @classmethod
+    def from_files(cls, fasta_path, gtf_path):
+        """Index::create_from_files (src/index.rs:52-223) in the native library."""
+        h = C.c_void_p()
+        rc = lib().thm_index_create_from_files(str(fasta_path).encode(), str(gtf_path).encode(), C.byref(h))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        return cls._wrap(h)
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        rc = lib().thm_index_load(str(path).encode(), C.byref(h))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        return cls._wrap(h)
+
+    def save(self, path):
+        rc = lib().thm_index_save(self.h, str(path).encode())
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+
+    def set_names(self, contig_names, tx_ids, gene_ids, gene_names):
+        a, b, c, d = (_cstr_array(x) for x in (contig_names, tx_ids, gene_ids, gene_names))
+        rc = lib().thm_index_set_names(self.h, a, len(contig_names), b, len(tx_ids), c, d, len(gene_ids))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+
+    def native_tables(self):
+        """Copy of the tables the native index holds, in the layout of refdata.build_tables."""
+        v = TablesView()
+        rc = lib().thm_index_tables(self.h, C.byref(v))
+        if rc != 0:
+            raise ThermiteError(rc, "thm_index_tables")
+        L = lib()
+        dec = lambda f, n: [f(self.h, i).decode() for i in range(n)]
+        names = dec(L.thm_index_contig_name, v.n_contigs)
+        refs = _copy(v.refs, v.n_refs, REF_DT)
+        rank_per_ref = _copy(v.name_rank, v.n_refs, "<u4")
+        name_rank = np.zeros(v.n_contigs, "<u4")
+        if v.n_contigs:
+            name_rank[refs["name_id"]] = rank_per_ref
+        have = v.n_contigs > 0
+        return dict(
+            text=_copy(v.text, v.n_text, np.uint8), refs=refs, names=names, name_rank=name_rank,
+            txs=_copy(v.txs, v.n_txs, TX_DT), exons=_copy(v.exons, v.n_exons, EXON_DT),
+            tx_seq=_copy(v.tx_seq, v.n_tx_seq, np.uint8), genes=_copy(v.genes, v.n_genes, SPAN_DT),
+            gene_ids=dec(L.thm_index_gene_id, v.n_genes) if have else [],
+            gene_names=dec(L.thm_index_gene_name, v.n_genes) if have else [],
+            tx_ids=dec(L.thm_index_tx_id, v.n_txs) if have else [],
+        )
 
     def __init__(self, tables, sa=None):
         t = tables
@@ -209,6 +342,8 @@ class Index:
         if rc != 0:
             raise ThermiteError(rc, (lib().thm_last_error(None) or b"").decode())
         self.h = h
+        if t.get("names") and "tx_ids" in t:
+            self.set_names(t["names"], t["tx_ids"], t["gene_ids"], t["gene_names"])
 
     def suffix_array(self):
         n = lib().thm_index_text_len(self.h)
@@ -344,3 +479,95 @@ class Aligner:
 
     def __del__(self):
         self.close()
+
+
+class FastqReader:
+    """thm_fastq: FASTQ / FASTA batcher (needletail::parse_fastx_file, src/aligner.rs:51-56)."""
+
+    def __init__(self, path):
+        h = C.c_void_p()
+        rc = lib().thm_fastq_open(str(path).encode(), C.byref(h))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        self.h = h
+
+    def next_batch(self, max_reads):
+        """-> dict(bases, offsets, quals (None for FASTA), names, name_off) or None at end of file"""
+        v = ReadBatch()
+        rc = lib().thm_fastq_next_batch(self.h, max_reads, C.byref(v))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        if v.n_reads == 0:
+            return None
+        off = _copy(v.offsets, v.n_reads + 1, "<u8")
+        noff = _copy(v.name_off, v.n_reads + 1, "<u8")
+        return dict(bases=_copy(v.bases, v.n_bases, np.uint8), offsets=off,
+                    quals=_copy(v.quals, v.n_bases, np.uint8) if v.quals else None,
+                    names=_copy(v.names, int(noff[-1]), np.uint8), name_off=noff)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().thm_fastq_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def read_batch_struct(batch):
+    """dict from FastqReader.next_batch (or the same keys) -> (ReadBatch, keep-alive list)"""
+    keep = [_u8(batch["bases"]), np.ascontiguousarray(batch["offsets"], "<u8"),
+            None if batch.get("quals") is None else _u8(batch["quals"]), _u8(batch["names"]),
+            np.ascontiguousarray(batch["name_off"], "<u8")]
+    rb = ReadBatch(len(keep[1]) - 1, len(keep[0]), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]), _ptr(keep[4]))
+    return rb, keep
+
+
+class Writer:
+    """thm_writer: SAM / PAF rendering (src/aln_writer.rs)."""
+
+    def __init__(self, index, fmt=FMT_SAM, n_threads=1):
+        h = C.c_void_p()
+        rc = lib().thm_writer_create(index.h, fmt, n_threads, C.byref(h))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        self.h = h
+        self.index = index
+
+    def header(self):
+        t = Text()
+        rc = lib().thm_writer_header(self.h, C.byref(t))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        return bytes(_copy(t.data, t.len, np.uint8))
+
+    def format_batch(self, batch, result):
+        """batch: dict as from FastqReader.next_batch; result: BatchResult -> bytes"""
+        rb, keep = read_batch_struct(batch)
+        offs = np.ascontiguousarray(result.offsets, "<u8")
+        v = BatchView(len(offs) - 1, len(result.alns), len(result.ops), _ptr(offs), _ptr(result.alns),
+                      _ptr(result.ops))
+        t = Text()
+        rc = lib().thm_writer_format_batch(self.h, C.byref(rb), C.byref(v), C.byref(t))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        return bytes(_copy(t.data, t.len, np.uint8))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().thm_writer_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def align_files(aligner, fastq_paths, output_path, fmt=FMT_SAM, batch_reads=0, n_threads=0):
+    """align_reads_from_file (src/aligner.rs:22-120): FASTQ files -> one SAM / PAF file; returns the run stats."""
+    paths = _cstr_array([str(p) for p in fastq_paths])
+    st = RunStats()
+    rc = lib().thm_align_files(aligner.h, paths, len(fastq_paths), str(output_path).encode(), fmt, batch_reads, n_threads,
+                               C.byref(st))
+    if rc != 0:
+        raise ThermiteError(rc, _last_error())
+    return {k: getattr(st, k) for k, _ in RunStats._fields_}

@@ -184,6 +184,8 @@ int32_t thm_aligner_set_opts(thm_aligner* a, const thm_align_opts* o) {
 
 void* thm_aligner_stream(thm_aligner* a) { return a ? (void*)a->stream : nullptr; }
 
+const thm_index* thm_aligner_index(const thm_aligner* a) { return a ? a->ix : nullptr; }
+
 int32_t thm_counters_get(thm_aligner* a, uint64_t out[THM_N_COUNTERS]) {
   if (!a || !out) return THM_ERR_INVALID_ARG;
   HIPCHK(a, hipSetDevice(a->device));

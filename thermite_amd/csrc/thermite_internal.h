@@ -101,6 +101,8 @@ struct thm_index {
   std::vector<uint32_t> exon_grid_off, gene_grid_off;
   std::vector<thm::GridEntry> exon_grid, gene_grid;
   uint64_t n = 0;
+  // names for the writer (Ref::name, Tx::id, Gene::{id,name}); empty when not supplied
+  std::vector<std::string> contig_names, tx_ids, gene_ids, gene_names;
   // per-device uploaded copy (guarded by dev_mu)
   struct DevCopy;
   std::vector<DevCopy*> dev;  // indexed by device id
