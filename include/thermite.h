@@ -257,8 +257,10 @@ const thm_index* thm_aligner_index(const thm_aligner*);
 
 /* aligner::align_read (src/aligner.rs:123-190) for a batch.  `bases` holds the
  * reads back to back, read r = bases[offsets[r] .. offsets[r+1]).  Host
- * buffers in, host view out (valid until the next call on this aligner or
- * thm_aligner_free). */
+ * buffers in, host view out.  Results land in two pinned host buffer sets
+ * used alternately: a view stays valid until the second-next fetch on this
+ * aligner (or thm_aligner_free), so a writer can render batch k while batch
+ * k+1 is uploaded, run and fetched. */
 int32_t thm_align_batch(thm_aligner*, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
                         thm_batch_view* out);
 

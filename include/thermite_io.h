@@ -102,7 +102,7 @@ typedef struct thm_text {
 } thm_text;
 
 typedef struct thm_writer thm_writer;
-/* n_threads formatting threads (0 = hardware concurrency, capped at 32) */
+/* n_threads formatting threads (0 = hardware concurrency, at most 16; explicit values up to 32) */
 int32_t thm_writer_create(const thm_index* ix, int32_t format, uint32_t n_threads, thm_writer** out);
 void thm_writer_free(thm_writer* w);
 /* build_sam_header, src/aln_writer.rs:256-276 (empty for PAF) */
@@ -130,7 +130,7 @@ typedef struct thm_run_stats {
 
 /* align_reads_from_file, src/aligner.rs:22-120: every record of every FASTQ in
  * order -> output_path ("-" = stdout).  Three overlapped stages (parse | GPU |
- * format+write) over batches of `batch_reads` reads (0 = 500 000). */
+ * format+write) over batches of `batch_reads` reads (0 = 250 000). */
 int32_t thm_align_files(thm_aligner* a, const char* const* fastq_paths, uint32_t n_paths, const char* output_path,
                         int32_t format, uint64_t batch_reads, uint32_t n_threads, thm_run_stats* stats);
 

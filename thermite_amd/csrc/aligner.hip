@@ -167,6 +167,11 @@ void thm_aligner_free(thm_aligner* a) {
                  &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops, &a->e_nalns,
                  &a->e_nalns64, &a->e_opbytes, &a->e_aln_off, &a->e_ops_off, &a->o_alns, &a->o_ops, &a->o_mems};
   for (DBuf* b : all) b->release();
+  for (int k = 0; k < 2; k++) {
+    a->r_off[k].release();
+    a->r_alns[k].release();
+    a->r_ops[k].release();
+  }
   for (auto& e : a->ev)
     if (e) (void)hipEventDestroy(e);
   if (a->stream) (void)hipStreamDestroy(a->stream);

@@ -36,6 +36,31 @@ struct DBuf {
   }
 };
 
+// grow-only pinned host buffer (results land here: D2H at full PCIe rate, no value-initialisation)
+struct HBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return (T*)p;
+  }
+};
+
 struct thm_index::DevCopy {
   int device = -1;
   DBuf text, sa, lut, refs, name_rank, txs, exons, exon_txoff, tx_seq, exon_grid_off, exon_grid, gene_grid_off, gene_grid;
@@ -84,7 +109,11 @@ struct thm_aligner {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float timings[THM_N_TIMINGS] = {0};
 
-  // host results
+  // host results of the read-level path: two pinned sets used alternately, so that the view
+  // thm_batch_fetch returned stays valid while the next batch is uploaded, run and fetched
+  HBuf r_off[2], r_alns[2], r_ops[2];
+  int r_cur = 0;
+  // host results of the operator- and seed-level calls
   std::vector<uint64_t> h_off;
   std::vector<thm_aln> h_alns;
   std::vector<uint8_t> h_ops;

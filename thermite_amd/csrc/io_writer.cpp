@@ -16,7 +16,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/thermite_io.h"
+#include "io_internal.h"
 #include "thermite_internal.h"
 
 struct thm_writer {
@@ -292,6 +292,42 @@ bool format_range(const Ctx& c, uint64_t r0, uint64_t r1, std::string& s, std::s
 
 }  // namespace
 
+namespace thm {
+
+int writer_format_chunks(thm_writer* w, const thm_read_batch* reads, const thm_batch_view* res,
+                         std::vector<const std::string*>& chunks) {
+  chunks.clear();
+  if (!w || !reads || !res) return THM_ERR_INVALID_ARG;
+  if (reads->n_reads != res->n_reads) return fail(THM_ERR_INVALID_ARG, "thm_writer_format_batch: reads and results differ in n_reads");
+  if (reads->n_reads && (!reads->offsets || !reads->name_off || !reads->names || !res->read_aln_off)) return THM_ERR_INVALID_ARG;
+  const uint64_t n = reads->n_reads;
+  const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(w->n_threads, (n + 4095) / 4096));
+  w->chunk.resize(std::max<size_t>(w->chunk.size(), T));
+  Ctx c{w->ix, reads, res, w->format};
+  std::vector<std::string> errs(T);
+  std::vector<char> ok(T, 1);
+  auto work = [&](unsigned t) {
+    std::string& s = w->chunk[t];
+    s.clear();
+    const uint64_t r0 = n * t / T, r1 = n * (t + 1) / T;
+    ok[t] = format_range(c, r0, r1, s, errs[t]) ? 1 : 0;
+  };
+  if (T == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+  }
+  for (unsigned t = 0; t < T; t++)
+    if (!ok[t]) return fail(THM_ERR_INTERNAL, "thm_writer_format_batch: " + errs[t]);
+  for (unsigned t = 0; t < T; t++) chunks.push_back(&w->chunk[t]);
+  return THM_OK;
+}
+
+}  // namespace thm
+
 extern "C" {
 
 int32_t thm_writer_create(const thm_index* ix, int32_t format, uint32_t n_threads, thm_writer** out) {
@@ -305,7 +341,7 @@ int32_t thm_writer_create(const thm_index* ix, int32_t format, uint32_t n_thread
   thm_writer* w = new thm_writer();
   w->ix = ix;
   w->format = format;
-  unsigned t = n_threads ? n_threads : std::thread::hardware_concurrency();
+  unsigned t = n_threads ? n_threads : std::min(16u, std::thread::hardware_concurrency());
   w->n_threads = std::max(1u, std::min(t, 32u));
   if (format == THM_FMT_SAM) {
     // build_sam_header (:256-276): the reference sequences are collected into a map keyed by name,
@@ -332,36 +368,15 @@ int32_t thm_writer_header(thm_writer* w, thm_text* out) {
 }
 
 int32_t thm_writer_format_batch(thm_writer* w, const thm_read_batch* reads, const thm_batch_view* res, thm_text* out) {
-  if (!w || !reads || !res || !out) return THM_ERR_INVALID_ARG;
-  if (reads->n_reads != res->n_reads) return fail(THM_ERR_INVALID_ARG, "thm_writer_format_batch: reads and results differ in n_reads");
-  if (reads->n_reads && (!reads->offsets || !reads->name_off || !reads->names || !res->read_aln_off)) return THM_ERR_INVALID_ARG;
-  const uint64_t n = reads->n_reads;
-  const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(w->n_threads, (n + 4095) / 4096));
-  w->chunk.resize(std::max<size_t>(w->chunk.size(), T));
-  Ctx c{w->ix, reads, res, w->format};
-  std::vector<std::string> errs(T);
-  std::vector<char> ok(T, 1);
-  auto work = [&](unsigned t) {
-    std::string& s = w->chunk[t];
-    s.clear();
-    const uint64_t r0 = n * t / T, r1 = n * (t + 1) / T;
-    ok[t] = format_range(c, r0, r1, s, errs[t]) ? 1 : 0;
-  };
-  if (T == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
-  }
-  for (unsigned t = 0; t < T; t++)
-    if (!ok[t]) return fail(THM_ERR_INTERNAL, "thm_writer_format_batch: " + errs[t]);
+  if (!out) return THM_ERR_INVALID_ARG;
+  std::vector<const std::string*> chunks;
+  const int rc = thm::writer_format_chunks(w, reads, res, chunks);
+  if (rc != THM_OK) return rc;
   size_t total = 0;
-  for (unsigned t = 0; t < T; t++) total += w->chunk[t].size();
+  for (const std::string* c : chunks) total += c->size();
   w->out.clear();
   w->out.reserve(total);
-  for (unsigned t = 0; t < T; t++) w->out += w->chunk[t];
+  for (const std::string* c : chunks) w->out += *c;
   out->data = (const uint8_t*)w->out.data();
   out->len = w->out.size();
   return THM_OK;

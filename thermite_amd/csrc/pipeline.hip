@@ -277,23 +277,28 @@ int32_t thm_batch_fetch(thm_aligner* a, thm_batch_view* out) {
   if (rc != THM_OK) return rc;
   const uint64_t n = a->n_reads;
   hipStream_t s = a->stream;
-  a->h_off.assign(n + 1, 0);
-  uint64_t n_ops = 0;
-  HIPCHK(a, hipMemcpyAsync(a->h_off.data(), a->e_aln_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(a, hipMemcpyAsync(&n_ops, a->e_ops_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+  const int k = a->r_cur ^= 1;  // the other set still backs the previous view
+  HBuf& h_off = a->r_off[k];
+  HBuf& h_alns = a->r_alns[k];
+  HBuf& h_ops = a->r_ops[k];
+  HIPCHK(a, h_off.ensure((n + 2) * 8));
+  // offsets, and behind them the op-pool size, in one round trip
+  HIPCHK(a, hipMemcpyAsync(h_off.p, a->e_aln_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(a, hipMemcpyAsync(h_off.as<uint64_t>() + n + 1, a->e_ops_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
   HIPCHK(a, hipStreamSynchronize(s));
-  const uint64_t n_alns = a->h_off[n];
-  a->h_alns.resize(n_alns);
-  a->h_ops.resize(n_ops);
-  if (n_alns) HIPCHK(a, hipMemcpyAsync(a->h_alns.data(), a->o_alns.p, n_alns * sizeof(thm_aln), hipMemcpyDeviceToHost, s));
-  if (n_ops) HIPCHK(a, hipMemcpyAsync(a->h_ops.data(), a->o_ops.p, n_ops, hipMemcpyDeviceToHost, s));
+  const uint64_t n_alns = h_off.as<uint64_t>()[n];
+  const uint64_t n_ops = h_off.as<uint64_t>()[n + 1];
+  HIPCHK(a, h_alns.ensure(n_alns * sizeof(thm_aln)));
+  HIPCHK(a, h_ops.ensure(n_ops));
+  if (n_alns) HIPCHK(a, hipMemcpyAsync(h_alns.p, a->o_alns.p, n_alns * sizeof(thm_aln), hipMemcpyDeviceToHost, s));
+  if (n_ops) HIPCHK(a, hipMemcpyAsync(h_ops.p, a->o_ops.p, n_ops, hipMemcpyDeviceToHost, s));
   HIPCHK(a, hipStreamSynchronize(s));
   out->n_reads = n;
   out->n_alns = n_alns;
   out->n_op_bytes = n_ops;
-  out->read_aln_off = a->h_off.data();
-  out->alns = a->h_alns.data();
-  out->ops = a->h_ops.data();
+  out->read_aln_off = h_off.as<uint64_t>();
+  out->alns = h_alns.as<thm_aln>();
+  out->ops = h_ops.as<uint8_t>();
   return THM_OK;
 }
 

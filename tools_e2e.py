@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""End-to-end file throughput on the GPU box (tuning aid, not the benchmark):
+FASTQ on disk -> thm_align_files -> SAM / PAF.   python tools_e2e.py [ref_len] [n_reads] [threads]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from thermite_amd import capi, synth
+
+ref_len = int(sys.argv[1]) if len(sys.argv) > 1 else 4000000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000000
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+t = synth.synth_reference(length=ref_len)
+ix = capi.Index(t)
+bases, off, _ = synth.simulate_reads(t, n, 91, sub_rate=0.01, indel_rate=0.001, stream=100)
+t0 = time.time()
+path = "/tmp/thm_e2e_%d.fastq" % n
+reads = bases.reshape(n, 91)
+qual = np.full(91, ord("F"), np.uint8)
+with open(path, "wb") as f:
+    CH = 100000
+    for s in range(0, n, CH):
+        e = min(n, s + CH)
+        parts = []
+        for i in range(s, e):
+            parts.append(b"@SYN:%d 1:N:0:ACGT\n" % i)
+            parts.append(reads[i].tobytes())
+            parts.append(b"\n+\n")
+            parts.append(qual.tobytes())
+            parts.append(b"\n")
+        f.write(b"".join(parts))
+print("fastq: %d reads, %.1f MB, written in %.1fs" % (n, os.path.getsize(path) / 1e6, time.time() - t0), flush=True)
+a = capi.Aligner(ix, capi.CI_OPTS)
+for fmt, name in ((capi.FMT_SAM, "sam"), (capi.FMT_PAF, "paf")):
+    for rep in range(2):
+        out = "/tmp/thm_e2e_out.%s" % name
+        st = capi.align_files(a, [path], out, fmt, batch_reads=500000, n_threads=threads)
+        print("%s run %d: %.2f Mreads/s wall %.2fs | parse %.2fs gpu %.2fs format %.2fs write %.2fs | %d batches, %.0f MB out" % (
+            name, rep, st["n_reads"] / st["wall_s"] / 1e6, st["wall_s"], st["parse_s"], st["gpu_s"], st["format_s"], st["write_s"],
+            st["n_batches"], st["n_output_bytes"] / 1e6), flush=True)
+a.close()
+os.remove(path)
