@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--read-len", type=int, default=91)
     ap.add_argument("--ref-len", type=int, default=int(os.environ.get("THM_BENCH_REF_LEN", "0")) or None)
     ap.add_argument("--opts", choices=["ci", "default"], default="ci")
+    ap.add_argument("--workload", choices=["chr21syn", "chrM"], default="chr21syn",
+                    help="chr21syn: the headline workload (BASELINE configs[2]); chrM: configs[1], the real chrM FASTA/GTF "
+                         "that ship with the reference's data/ (copied to tests/golden/data)")
+    ap.add_argument("--percent", type=float, default=None, help="override min_aln_score_percent (config 5: 0.574 at 150 bp = band +-64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -86,15 +90,25 @@ def main():
     from thermite_amd import capi, synth
 
     # ---------------- workload ----------------
-    ref_len = args.ref_len or synth.CHR21_LEN
     t0 = time.time()
-    tables = synth.synth_reference(length=ref_len)
-    tag = "%d_%x" % (ref_len, synth.SEED)
+    if args.workload == "chrM":
+        from thermite_amd import refdata
+
+        d = os.path.join(ROOT, "tests", "golden", "data")
+        tables = refdata.load_reference(d + "/GRCh38-2020-A-chrM.fasta", d + "/GRCh38-2020-A-chrM.gtf")
+        ref_len = int(tables["refs"][0]["len"])
+        tag = "chrM"
+    else:
+        ref_len = args.ref_len or synth.CHR21_LEN
+        tables = synth.synth_reference(length=ref_len)
+        tag = "%d_%x" % (ref_len, synth.SEED)
     sa = load_suffix_array(capi, tables, rank, world, dist, tag)
     index = capi.Index(tables, sa=sa)
-    log(rank, "reference: %d bp synthetic, text n=%d, %d transcripts, %d exons; index in %.1fs" % (
-        ref_len, len(tables["text"]), len(tables["txs"]), len(tables["exons"]), time.time() - t0))
-    opts = capi.CI_OPTS if args.opts == "ci" else capi.DEFAULT_OPTS
+    log(rank, "reference: %s %d bp, text n=%d, %d transcripts, %d exons; index in %.1fs" % (
+        args.workload, ref_len, len(tables["text"]), len(tables["txs"]), len(tables["exons"]), time.time() - t0))
+    opts = dict(capi.CI_OPTS if args.opts == "ci" else capi.DEFAULT_OPTS)
+    if args.percent is not None:
+        opts["min_aln_score_percent"] = args.percent
     L = args.read_len
     bases, offsets, _ = synth.simulate_reads(tables, args.reads_per_gpu, L, sub_rate=0.01, indel_rate=0.001,
                                              stream=100 + rank)
@@ -157,7 +171,8 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("reads_per_gpu") == n_r and tj.get("ref_len") == ref_len and tj.get("opts") == args.opts:
+            if (tj.get("reads_per_gpu") == n_r and tj.get("ref_len") == ref_len and tj.get("opts") == args.opts
+                    and args.workload == "chr21syn" and args.percent is None and L == 91):
                 traffic = tj.get("extend_kernel_hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -206,9 +221,12 @@ def main():
             "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {
-                "workload": "%d synthetic %d bp reads per GPU vs chr21-sized synthetic transcriptome (%d bp, %d tx), "
-                            "flags %s" % (args.reads_per_gpu, L, ref_len, len(tables["txs"]),
-                                          "-k20 -s0 --intron-mode" if args.opts == "ci" else "defaults (-k20 -s0.66)"),
+                "workload": "%d synthetic %d bp reads per GPU vs %s (%d bp, %d tx), flags %s%s" % (
+                    args.reads_per_gpu, L,
+                    "chr21-sized synthetic transcriptome" if args.workload == "chr21syn" else "GRCh38-2020-A chrM (real FASTA/GTF)",
+                    ref_len, len(tables["txs"]),
+                    "-k20 -s0 --intron-mode" if args.opts == "ci" else "defaults (-k20 -s0.66)",
+                    "" if args.percent is None else " with -s%g" % args.percent),
                 "reads_per_gpu": args.reads_per_gpu, "read_len": L, "ref_len": ref_len, "opts": args.opts,
                 "parallelism": "reads sharded over %d GPU(s), index replicated, 1 counter all-reduce" % world,
             },

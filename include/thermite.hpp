@@ -10,17 +10,21 @@
 //     Aligner::align_reads     <->  the loop of align_reads_from_file, src/aligner.rs:51-56, batched
 //     Aligner::all_smems       <->  Index::all_smems          src/index.rs:228
 //     Aligner::swg_extend      <->  SwgExtend::extend         src/swg.rs:31
+//     thermite::ThermiteAligner<->  wrapper::ThermiteAligner  src/wrapper.rs:20-123 (index file in, SAM records out)
+//     thermite::align_reads_from_file <-> aligner::align_reads_from_file  src/aligner.rs:22-120
 // Errors that are panics in the reference are exceptions here (never across the C ABI).
 #ifndef THERMITE_AMD_THERMITE_HPP
 #define THERMITE_AMD_THERMITE_HPP
 
 #include <cstdint>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "thermite.h"
+#include "thermite_io.h"
 
 namespace thermite {
 
@@ -84,9 +88,28 @@ class Index {
     if (rc != THM_OK) throw Error(rc, thm_last_error(nullptr));
     h_.reset(h, thm_index_free);
   }
+  // Index::create_from_files, src/index.rs:52-223
+  static Index from_files(const std::string& fasta_path, const std::string& gtf_path) {
+    thm_index* h = nullptr;
+    const int rc = thm_index_create_from_files(fasta_path.c_str(), gtf_path.c_str(), &h);
+    if (rc != THM_OK) throw Error(rc, thm_last_error(nullptr));
+    return Index(h);
+  }
+  // the index file written by save() (the reference's .tai role, src/main.rs:37-43)
+  static Index load(const std::string& path) {
+    thm_index* h = nullptr;
+    const int rc = thm_index_load(path.c_str(), &h);
+    if (rc != THM_OK) throw Error(rc, thm_last_error(nullptr));
+    return Index(h);
+  }
+  void save(const std::string& path) const {
+    const int rc = thm_index_save(h_.get(), path.c_str());
+    if (rc != THM_OK) throw Error(rc, thm_last_error(nullptr));
+  }
   const thm_index* get() const { return h_.get(); }
 
  private:
+  explicit Index(thm_index* h) : h_(h, thm_index_free) {}
   std::shared_ptr<thm_index> h_;  // Arc<Index>, src/wrapper.rs:22
 };
 
@@ -149,6 +172,10 @@ class Aligner {
     return SwgAlignment{v.alns[0].score, v.alns[0].xend, v.alns[0].yend, decode_ops(v.ops + v.alns[0].ops_off, v.alns[0].ops_len)};
   }
   thm_aligner* get() { return h_.get(); }
+  void set_opts(const AlignOpts& opts) {
+    thm_align_opts o = opts.c();
+    check(thm_aligner_set_opts(h_.get(), &o));
+  }
 
  private:
   void check(int rc) {
@@ -156,6 +183,85 @@ class Aligner {
   }
   Index index_;
   std::shared_ptr<thm_aligner> h_;
+};
+
+enum class OutputFormat { Paf = THM_FMT_PAF, Sam = THM_FMT_SAM };  // src/aln_writer.rs:16-21 (BAM is not built)
+
+// aligner::align_reads_from_file, src/aligner.rs:22-120
+inline thm_run_stats align_reads_from_file(Aligner& aligner, const std::vector<std::string>& query_paths,
+                                           const std::string& output_path, OutputFormat output_fmt,
+                                           std::uint64_t batch_reads = 0, unsigned n_threads = 0) {
+  std::vector<const char*> p;
+  for (const auto& q : query_paths) p.push_back(q.c_str());
+  thm_run_stats st;
+  const int rc = thm_align_files(aligner.get(), p.data(), (std::uint32_t)p.size(), output_path.c_str(), (int)output_fmt,
+                                 batch_reads, n_threads, &st);
+  if (rc != THM_OK) throw Error(rc, thm_last_error(nullptr));
+  return st;
+}
+
+// wrapper::ThermiteAligner, src/wrapper.rs:20-123: index file in, one read per call, SAM records out.
+// align_read returns the records as SAM text lines (the reference converts the same text to
+// rust_htslib Records and strips the TX/GX/GN/RE tags there, src/wrapper.rs:126-141).
+class ThermiteAligner {
+ public:
+  explicit ThermiteAligner(const std::string& index_path, int device = 0)
+      : index_(Index::load(index_path)), aligner_(index_, AlignOpts{}, device) {  // default settings, src/wrapper.rs:40-46
+    thm_writer* w = nullptr;
+    const int rc = thm_writer_create(index_.get(), THM_FMT_SAM, 1, &w);
+    if (rc != THM_OK) throw Error(rc, thm_last_error(nullptr));
+    writer_.reset(w, thm_writer_free);
+    thm_text t;
+    thm_writer_header(w, &t);
+    header_.assign((const char*)t.data, t.len);
+  }
+  std::vector<std::string> align_read(const std::string& name, const std::string& read, const std::string& qual) {
+    aligner_.set_opts(opts_);
+    const std::uint64_t off[2] = {0, read.size()}, noff[2] = {0, name.size()};
+    thm_batch_view v;
+    int rc = thm_align_batch(aligner_.get(), (const std::uint8_t*)read.data(), off, 1, &v);
+    if (rc != THM_OK) throw Error(rc, thm_last_error(aligner_.get()));
+    thm_read_batch rb;
+    rb.n_reads = 1;
+    rb.n_bases = read.size();
+    rb.bases = (const std::uint8_t*)read.data();
+    rb.offsets = off;
+    rb.quals = qual.size() == read.size() ? (const std::uint8_t*)qual.data() : nullptr;
+    rb.names = (const std::uint8_t*)name.data();
+    rb.name_off = noff;
+    thm_text t;
+    rc = thm_writer_format_batch(writer_.get(), &rb, &v, &t);
+    if (rc != THM_OK) throw Error(rc, thm_last_error(nullptr));
+    std::vector<std::string> out;
+    const char* p = (const char*)t.data;
+    const char* e = p + t.len;
+    while (p < e) {
+      const char* nl = p;
+      while (nl < e && *nl != '\n') nl++;
+      out.emplace_back(p, nl);  // omit the newline, src/wrapper.rs:132-133
+      p = nl + 1;
+    }
+    return out;
+  }
+  // the size of the index file, src/wrapper.rs:104-108
+  static std::size_t est_mem(const std::string& index_path) {
+    FILE* f = fopen(index_path.c_str(), "rb");
+    if (!f) throw Error(THM_ERR_IO, "Failed to open " + index_path);
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fclose(f);
+    return (std::size_t)n;
+  }
+  const AlignOpts& opts() const { return opts_; }
+  AlignOpts& opts_mut() { return opts_; }
+  const std::string& header_view() const { return header_; }  // SAM header text (a HeaderView in the reference)
+
+ private:
+  Index index_;
+  Aligner aligner_;
+  AlignOpts opts_;
+  std::shared_ptr<thm_writer> writer_;
+  std::string header_;
 };
 
 }  // namespace thermite

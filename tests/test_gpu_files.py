@@ -74,3 +74,20 @@ def test_align_files_reports_errors(data_dir, tmp_path):
         capi.align_files(a, [data_dir + "/test_query.fastq"], tmp_path / "o.bam", capi.FMT_BAM)
     assert e.value.code == capi.ERR_UNSUPPORTED
     a.close()
+
+
+def test_cpp_thermite_aligner_wrapper(data_dir, golden_dir, tmp_path):
+    """include/thermite.hpp's ThermiteAligner (src/wrapper.rs:20-123) compiled and run: index file in,
+    one read per call, the SAM records of config 1 out"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "wrapper_main"
+    libdir = os.path.dirname(capi.SO_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "wrapper_main.cpp"), "-o", str(exe), "-L" + libdir,
+                           "-lthermite_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    idx = tmp_path / "test_ref.thmidx"
+    capi.Index.from_files(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf").save(idx)
+    out = subprocess.run([str(exe), str(idx), "3", "0", data_dir + "/test_query.fastq"], check=True, capture_output=True)
+    assert out.stdout == open(os.path.join(golden_dir, "test_query.sam"), "rb").read()
+    assert ("est_mem %d" % os.path.getsize(idx)).encode() in out.stderr
