@@ -217,7 +217,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "aligned reads/sec (91 bp)", "value": round(value, 1), "unit": "reads/s", "n_gpus": world,
+            "metric": "aligned reads/sec (%d bp)" % L, "value": round(value, 1), "unit": "reads/s", "n_gpus": world,
             "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {
