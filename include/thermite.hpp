@@ -185,7 +185,7 @@ class Aligner {
   std::shared_ptr<thm_aligner> h_;
 };
 
-enum class OutputFormat { Paf = THM_FMT_PAF, Sam = THM_FMT_SAM };  // src/aln_writer.rs:16-21 (BAM is not built)
+enum class OutputFormat { Paf = THM_FMT_PAF, Sam = THM_FMT_SAM, Bam = THM_FMT_BAM };  // src/aln_writer.rs:16-21
 
 // aligner::align_reads_from_file, src/aligner.rs:22-120
 inline thm_run_stats align_reads_from_file(Aligner& aligner, const std::vector<std::string>& query_paths,

@@ -94,7 +94,7 @@ void thm_fastq_close(thm_fastq* r);
 /* -------------------------------------------------------- SAM / PAF writer */
 
 /* OutputFormat, src/aln_writer.rs:16-21 */
-enum { THM_FMT_PAF = 0, THM_FMT_SAM = 1, THM_FMT_BAM = 2 /* not built: THM_ERR_UNSUPPORTED */ };
+enum { THM_FMT_PAF = 0, THM_FMT_SAM = 1, THM_FMT_BAM = 2 };
 
 typedef struct thm_text {
   const uint8_t* data;
@@ -105,12 +105,18 @@ typedef struct thm_writer thm_writer;
 /* n_threads formatting threads (0 = hardware concurrency, at most 16; explicit values up to 32) */
 int32_t thm_writer_create(const thm_index* ix, int32_t format, uint32_t n_threads, thm_writer** out);
 void thm_writer_free(thm_writer* w);
-/* build_sam_header, src/aln_writer.rs:256-276 (empty for PAF) */
+/* build_sam_header, src/aln_writer.rs:256-276 (empty for PAF; for BAM the
+ * BGZF-compressed magic + header text + reference list of bam::Writer::write_header
+ * / write_reference_sequences, src/aligner.rs:41-46) */
 int32_t thm_writer_header(thm_writer* w, thm_text* out);
+/* what closes the file: the BGZF end-of-file block for BAM, nothing otherwise */
+int32_t thm_writer_trailer(thm_writer* w, thm_text* out);
 /* aln_to_sam_record / unmapped_sam_record / PafEntry, src/aln_writer.rs:47-253,
  * applied in the order of the writer loop src/aligner.rs:58-115: the records
  * of `reads` rendered from `result` (= what thm_align_batch / thm_batch_fetch
- * returned for exactly these reads).  Text valid until the next call on `w`. */
+ * returned for exactly these reads).  For BAM the result is a run of complete
+ * BGZF blocks (records re-encoded in binary, bam::Writer::write_sam_record,
+ * src/aligner.rs:69-76,98-108).  Text valid until the next call on `w`. */
 int32_t thm_writer_format_batch(thm_writer* w, const thm_read_batch* reads, const thm_batch_view* result, thm_text* out);
 
 /* ------------------------------------------------------ whole-file driver */

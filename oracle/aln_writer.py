@@ -162,3 +162,138 @@ def format_batch(tables, names, seqs, quals, result, fmt):
             else:
                 out.append(paf_record(tables, names[r], seqs[r], aln, ops, a1 - a0))
     return b"".join(out)
+
+
+# ------------------------------------------------------------------ BAM
+# The reference writes BAM with noodles-bam 0.1.0 (`write_sam_record`, src/aligner.rs:69-76,98-108;
+# header src/aligner.rs:41-46).  noodles is not in the checkout: the binary layout below is the
+# SAM/BAM specification's (parity unpinned); BGZF framing is checked separately by the tests and
+# parity is defined on the decompressed stream.
+import struct
+
+_SEQ_CODE = {c: i for i, c in enumerate(b"=ACMGRSVTWYHKDBN")}
+_CIG_CODE = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4}
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def _sq_list(tables):
+    names, out = {}, []
+    for r in tables["refs"]:
+        nm = tables["names"][int(r["name_id"])]
+        if nm not in names:
+            names[nm] = len(out)
+            out.append((nm, int(r["len"])))
+    return names, out
+
+
+def bam_header_bytes(tables):
+    text = sam_header(tables)
+    _, sq = _sq_list(tables)
+    out = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(sq))
+    for nm, ln in sq:
+        out += struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln)
+    return out
+
+
+def _int_tag(tag, v):
+    if v >= 0:
+        if v <= 0xFF:
+            return tag + b"C" + struct.pack("<B", v)
+        if v <= 0xFFFF:
+            return tag + b"S" + struct.pack("<H", v)
+        return tag + b"I" + struct.pack("<I", v)
+    if v >= -128:
+        return tag + b"c" + struct.pack("<b", v)
+    if v >= -32768:
+        return tag + b"s" + struct.pack("<h", v)
+    return tag + b"i" + struct.pack("<i", v)
+
+
+def _bam_record(qname, flag, ref_id, pos, mapq, cigar, seq, qual, tags):
+    import re
+
+    ops = [] if cigar == "*" else [(int(n), k) for n, k in re.findall(r"(\d+)([MIDNS])", cigar)]
+    ref_len = sum(n for n, k in ops if k in "MDN")
+    bin_ = 4680 if pos < 0 else _reg2bin(pos, pos + max(ref_len, 1))
+    body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(qname) + 1, mapq, bin_, len(ops), flag, len(seq), -1, -1, 0)
+    body += qname + b"\0"
+    body += b"".join(struct.pack("<I", (n << 4) | _CIG_CODE[k]) for n, k in ops)
+    codes = [_SEQ_CODE.get(c, _SEQ_CODE.get(c - 32, 15) if 97 <= c <= 122 else 15) for c in seq]
+    if len(codes) % 2:
+        codes.append(0)
+    body += bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+    body += bytes([0xFF] * len(seq)) if not qual else bytes(q - 33 for q in qual)
+    body += tags
+    return struct.pack("<i", len(body)) + body
+
+
+def bam_stream(tables, names, seqs, quals, result):
+    """the uncompressed BAM stream: header, then the records of the writer loop (src/aligner.rs:54-116)"""
+    sq_of, _ = _sq_list(tables)
+    out = [bam_header_bytes(tables)]
+    for r in range(len(seqs)):
+        a0, a1 = int(result.offsets[r]), int(result.offsets[r + 1])
+        qn = format_read_name(names[r])
+        if a0 == a1:
+            out.append(_bam_record(qn, 4, -1, -1, 255, "*", bytes(seqs[r]), bytes(quals[r]), b""))
+            continue
+        for i, a in enumerate(range(a0, a1)):
+            aln = result.alns[a]
+            ops = _ops(result, aln["ops_off"], aln["ops_len"])
+            strand = bool(aln["strand"])
+            seq = bytes(seqs[r]) if strand else revcomp(seqs[r])
+            qual = bytes(quals[r]) if strand else bytes(quals[r])[::-1]
+            tags = (_int_tag(b"AS", int(aln["score"])) + _int_tag(b"NH", a1 - a0) + _int_tag(b"HI", i + 1)
+                    + _int_tag(b"nM", sum(1 for o in ops if o == "Subst")))
+            t = int(aln["aln_type"])
+            if t == 0:
+                tx = int(aln["tx_or_gene_idx"])
+                g = int(tables["txs"][tx]["gene_idx"])
+                tx_ops = _ops(result, aln["tx_ops_off"], aln["tx_ops_len"])
+                tags += b"TXZ" + ("%s,+%d,%s" % (tables["tx_ids"][tx], int(aln["tx_ystart"]), to_cigar(tx_ops))).encode() + b"\0"
+                tags += b"GXZ" + tables["gene_ids"][g].encode() + b"\0" + b"GNZ" + tables["gene_names"][g].encode() + b"\0" + b"REAE"
+            elif t == 1:
+                g = int(aln["tx_or_gene_idx"])
+                tags += b"GXZ" + tables["gene_ids"][g].encode() + b"\0" + b"GNZ" + tables["gene_names"][g].encode() + b"\0" + b"REAN"
+            else:
+                tags += b"REAI"
+            ref_name = tables["names"][int(tables["refs"][int(aln["ref_id"])]["name_id"])]
+            flag = (0 if strand else 16) | (0 if aln["primary"] else 256)
+            out.append(_bam_record(qn, flag, sq_of[ref_name], int(aln["ystart"]), multimapq(a1 - a0), to_cigar(ops), seq, qual, tags))
+    return b"".join(out)
+
+
+def bgzf_decompress(data):
+    """Checks the BGZF framing block by block (gzip member with the BC extra field, sizes, CRC, the
+    28-byte end-of-file block last) and returns the concatenated payload."""
+    import zlib
+
+    out, off, last_len = [], 0, None
+    while off < len(data):
+        hdr = data[off: off + 18]
+        assert hdr[:4] == b"\x1f\x8b\x08\x04" and hdr[10:12] == b"\x06\x00" and hdr[12:16] == b"BC\x02\x00", "not a BGZF block"
+        bsize = struct.unpack("<H", hdr[16:18])[0] + 1
+        block = data[off: off + bsize]
+        assert len(block) == bsize, "truncated BGZF block"
+        payload = zlib.decompress(block[18:-8], -15)
+        crc, isize = struct.unpack("<II", block[-8:])
+        assert isize == len(payload) and crc == (zlib.crc32(payload) & 0xFFFFFFFF) and isize <= 65536
+        out.append(payload)
+        last_len = isize
+        off += bsize
+    assert last_len == 0 and data[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"), "no EOF block"
+    return b"".join(out)

@@ -22,6 +22,15 @@ def test_test_query_files_match_goldens(data_dir, golden_dir, tmp_path):
         st = capi.align_files(a, [data_dir + "/test_query.fastq"], out, fmt, batch_reads=4, n_threads=2)
         assert open(out, "rb").read() == open(os.path.join(golden_dir, name), "rb").read()
         assert st["n_reads"] == 10 and st["n_batches"] == 3 and st["n_aligned_reads"] == 8
+    # BAM: same records, binary, in BGZF blocks
+    t = refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    names, seqs, quals = refdata.parse_fastq(data_dir + "/test_query.fastq")
+    bases, off = refdata.pack_reads(seqs)
+    res = orc.Index(t).align_batch(bases, off, dict(capi.DEFAULT_OPTS, min_seed_len=3, min_aln_score=0))
+    out = tmp_path / "test_query.bam"
+    capi.align_files(a, [data_dir + "/test_query.fastq"], out, capi.FMT_BAM, batch_reads=4, n_threads=2)
+    assert ow.bgzf_decompress(open(out, "rb").read()) == ow.bam_stream(
+        t, [n.encode() for n in names], [bytes(x) for x in seqs], [bytes(q) for q in quals], res)
     a.close()
 
 
@@ -48,14 +57,18 @@ def test_chrM_fastq_to_sam_matches_oracle(data_dir, tmp_path, opts_name):
     idx_path = tmp_path / "chrM.thmidx"
     ix.save(idx_path)
     a = capi.Aligner(capi.Index.load(idx_path), opts)  # through the index container, like `thermite align <index>`
-    for fmt, key in ((capi.FMT_SAM, "sam"), (capi.FMT_PAF, "paf")):
+    for fmt, key in ((capi.FMT_SAM, "sam"), (capi.FMT_PAF, "paf"), (capi.FMT_BAM, "bam")):
         out = tmp_path / ("out." + key)
         st = capi.align_files(a, [p1, p2], out, fmt, batch_reads=777, n_threads=4)
-        want = (ow.sam_header(t) if key == "sam" else b"") + ow.format_batch(t, names, seqs, quals, res, key)
         got = open(out, "rb").read()
-        assert got == want, key
-        assert st["n_reads"] == n and st["n_output_bytes"] == len(want)
-        assert st["n_aligned_reads"] == int(res.counters[1])
+        if key == "bam":
+            assert ow.bgzf_decompress(got) == ow.bam_stream(t, names, seqs, quals, res)
+            assert st["n_output_bytes"] == len(got)
+        else:
+            want = (ow.sam_header(t) if key == "sam" else b"") + ow.format_batch(t, names, seqs, quals, res, key)
+            assert got == want, key
+            assert st["n_output_bytes"] == len(want)
+        assert st["n_reads"] == n and st["n_aligned_reads"] == int(res.counters[1])
     a.close()
 
 
@@ -71,8 +84,11 @@ def test_align_files_reports_errors(data_dir, tmp_path):
         capi.align_files(a, [bad], tmp_path / "o.sam", capi.FMT_SAM)
     assert e.value.code == capi.ERR_FORMAT
     with pytest.raises(capi.ThermiteError) as e:
-        capi.align_files(a, [data_dir + "/test_query.fastq"], tmp_path / "o.bam", capi.FMT_BAM)
-    assert e.value.code == capi.ERR_UNSUPPORTED
+        capi.align_files(a, [data_dir + "/test_query.fastq"], tmp_path / "o.xyz", 7)
+    assert e.value.code == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.align_files(a, [data_dir + "/test_query.fastq"], tmp_path / "no_such_dir" / "o.sam", capi.FMT_SAM)
+    assert e.value.code == capi.ERR_IO
     a.close()
 
 

@@ -176,6 +176,14 @@ def _check_writer(tables, names, seqs, quals, res):
                 sam = want
             else:
                 assert w.header() == b""
+            assert w.trailer() == b""
+    # BAM: the decompressed stream (header, records) must equal the oracle's; BGZF framing is checked on the way
+    bn = [n if isinstance(n, bytes) else n.encode() for n in names]
+    want = ow.bam_stream(tables, bn, seqs, quals, res)
+    for threads in (1, 3):
+        w = capi.Writer(ix, capi.FMT_BAM, threads)
+        blob = w.header() + w.format_batch(batch, res) + w.trailer()
+        assert ow.bgzf_decompress(blob) == want, ("bam", threads)
     return sam
 
 

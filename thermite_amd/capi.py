@@ -108,7 +108,7 @@ IO_ABI_SYMBOLS = [
     "thm_index_create_from_files", "thm_index_set_names", "thm_index_save", "thm_index_load", "thm_index_tables",
     "thm_index_contig_name", "thm_index_tx_id", "thm_index_gene_id", "thm_index_gene_name", "thm_fastq_open",
     "thm_fastq_next_batch", "thm_fastq_close", "thm_writer_create", "thm_writer_free", "thm_writer_header",
-    "thm_writer_format_batch", "thm_align_files",
+    "thm_writer_format_batch", "thm_writer_trailer", "thm_align_files",
 ]
 ERR_IO, ERR_FORMAT = -8, -9
 FMT_PAF, FMT_SAM, FMT_BAM = 0, 1, 2
@@ -193,6 +193,8 @@ def lib():
     L.thm_writer_free.argtypes = [vp]
     L.thm_writer_header.restype = i32
     L.thm_writer_header.argtypes = [vp, vp]
+    L.thm_writer_trailer.restype = i32
+    L.thm_writer_trailer.argtypes = [vp, vp]
     L.thm_writer_format_batch.restype = i32
     L.thm_writer_format_batch.argtypes = [vp, vp, vp, vp]
     L.thm_align_files.restype = i32
@@ -537,6 +539,13 @@ class Writer:
     def header(self):
         t = Text()
         rc = lib().thm_writer_header(self.h, C.byref(t))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        return bytes(_copy(t.data, t.len, np.uint8))
+
+    def trailer(self):
+        t = Text()
+        rc = lib().thm_writer_trailer(self.h, C.byref(t))
         if rc != 0:
             raise ThermiteError(rc, _last_error())
         return bytes(_copy(t.data, t.len, np.uint8))

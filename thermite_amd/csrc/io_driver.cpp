@@ -163,6 +163,11 @@ extern "C" int32_t thm_align_files(thm_aligner* a, const char* const* fastq_path
     for (;;) {
       Slot* s = q_aligned.pop();
       if (s->last) {
+        if (!sh.failed() && thm_writer_trailer(w, &t) == THM_OK && t.len) {
+          if (!write_all((const char*)t.data, t.len, file_off)) sh.set(THM_ERR_IO, "short write");
+          file_off += t.len;
+          st.n_output_bytes += t.len;
+        }
         q_free.push(s);
         break;
       }
@@ -198,7 +203,7 @@ extern "C" int32_t thm_align_files(thm_aligner* a, const char* const* fastq_path
           for (uint64_t r = 0; r < v.n_reads; r++) {
             const uint64_t k = v.read_aln_off[r + 1] - v.read_aln_off[r];
             st.n_aligned_reads += k != 0;
-            st.n_records += k ? k : (format == THM_FMT_SAM ? 1 : 0);
+            st.n_records += k ? k : (format == THM_FMT_PAF ? 0 : 1);
           }
         }
       }

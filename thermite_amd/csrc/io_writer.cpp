@@ -10,6 +10,8 @@
 // and the record order of the writer loop, src/aligner.rs:58-115.  The text
 // layout of a SAM line is noodles-sam 0.1.0's Display (Cargo.lock:773-776; not in
 // the reference checkout: restated from the SAM specification, parity unpinned).
+#include <zlib.h>
+
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -23,8 +25,11 @@ struct thm_writer {
   const thm_index* ix = nullptr;
   int format = THM_FMT_SAM;
   unsigned n_threads = 1;
-  std::string header;
-  std::vector<std::string> chunk;  // per formatting thread
+  std::string header;                // SAM text header; for BAM: the BGZF-compressed BAM header
+  std::string trailer;               // BAM: the BGZF end-of-file block
+  std::vector<int32_t> sq_of_name;   // contig name_id -> index of its @SQ line (BAM refID)
+  std::vector<std::string> chunk;    // per formatting thread
+  std::vector<std::string> raw;      // BAM: uncompressed records per formatting thread
   std::string out;
   std::string err;
 };
@@ -290,6 +295,277 @@ bool format_range(const Ctx& c, uint64_t r0, uint64_t r1, std::string& s, std::s
   return true;
 }
 
+
+// ---------------------------------------------------------------- BAM
+// The reference writes BAM through noodles-bam 0.1.0 (`write_sam_record`, src/aligner.rs:69-76,98-108):
+// the SAM record re-encoded in binary inside BGZF blocks.  Restated from the SAM/BAM specification
+// (noodles is not in the reference checkout: parity unpinned; compressed bytes depend on the deflate
+// implementation, so parity is defined on the decompressed stream).
+
+inline void le32(std::string& s, uint32_t v) {
+  char b[4] = {(char)(v & 0xff), (char)((v >> 8) & 0xff), (char)((v >> 16) & 0xff), (char)((v >> 24) & 0xff)};
+  s.append(b, 4);
+}
+inline void le16(std::string& s, uint32_t v) {
+  char b[2] = {(char)(v & 0xff), (char)((v >> 8) & 0xff)};
+  s.append(b, 2);
+}
+
+// UCSC binning scheme, SAM specification section 5.3
+inline uint32_t reg2bin(int64_t beg, int64_t end) {
+  --end;
+  if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+  if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+  if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+  if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+  if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+  return 0;
+}
+
+struct SeqCode {
+  uint8_t t[256];
+  SeqCode() {
+    for (int i = 0; i < 256; i++) t[i] = 15;
+    const char* a = "=ACMGRSVTWYHKDBN";
+    for (int i = 0; a[i]; i++) {
+      t[(uint8_t)a[i]] = (uint8_t)i;
+      if (a[i] >= 'A' && a[i] <= 'Z') t[(uint8_t)a[i] + 32] = (uint8_t)i;
+    }
+  }
+};
+const SeqCode SEQ_CODE;
+
+// integer tag with the smallest type that holds the value (c C s S i I)
+inline void bam_int_tag(std::string& s, const char* tag, int64_t v) {
+  s.append(tag, 2);
+  if (v >= 0) {
+    if (v <= 0xff) {
+      s.push_back('C');
+      s.push_back((char)v);
+    } else if (v <= 0xffff) {
+      s.push_back('S');
+      le16(s, (uint32_t)v);
+    } else {
+      s.push_back('I');
+      le32(s, (uint32_t)v);
+    }
+  } else {
+    if (v >= -128) {
+      s.push_back('c');
+      s.push_back((char)(int8_t)v);
+    } else if (v >= -32768) {
+      s.push_back('s');
+      le16(s, (uint32_t)(uint16_t)(int16_t)v);
+    } else {
+      s.push_back('i');
+      le32(s, (uint32_t)(int32_t)v);
+    }
+  }
+}
+inline void bam_str_tag(std::string& s, const char* tag, const std::string& v) {
+  s.append(tag, 2);
+  s.push_back('Z');
+  s += v;
+  s.push_back('\0');
+}
+
+// CIGAR of an op stream as BAM words; returns the reference length it consumes
+bool bam_cigar(std::vector<uint32_t>& out, const uint8_t* p, size_t n, OpCounts* cnt, uint64_t& ref_len) {
+  out.clear();
+  ref_len = 0;
+  static const uint32_t CODE[6] = {0 /*M*/, 0, 2 /*D*/, 1 /*I*/, 4 /*S*/, 3 /*N*/};
+  int prev_k = -1;
+  uint32_t prev_clip = 0;
+  uint64_t run = 0;
+  auto flush = [&]() {
+    if (prev_k < 0) return;
+    const uint64_t len = prev_k >= THM_OP_XCLIP ? (uint64_t)prev_clip : run;
+    out.push_back((uint32_t)(len << 4) | CODE[prev_k]);
+    if (prev_k == THM_OP_MATCH || prev_k == THM_OP_DEL || prev_k == THM_OP_YCLIP) ref_len += len;
+  };
+  for (size_t i = 0; i < n;) {
+    int k = p[i++];
+    uint32_t clip = 0;
+    if (k > THM_OP_YCLIP) return false;
+    if (k >= THM_OP_XCLIP) {
+      if (i + 4 > n) return false;
+      clip = (uint32_t)p[i] | ((uint32_t)p[i + 1] << 8) | ((uint32_t)p[i + 2] << 16) | ((uint32_t)p[i + 3] << 24);
+      i += 4;
+    }
+    if (cnt) {
+      cnt->n_match += k == THM_OP_MATCH;
+      cnt->n_subst += k == THM_OP_SUBST;
+      cnt->n_not_yclip += k != THM_OP_YCLIP;
+    }
+    if (k == THM_OP_SUBST) k = THM_OP_MATCH;
+    if (k == prev_k && (k < THM_OP_XCLIP || clip == prev_clip)) {
+      run++;
+    } else {
+      flush();
+      prev_k = k;
+      prev_clip = clip;
+      run = 1;
+    }
+  }
+  flush();
+  return true;
+}
+
+void bam_seq_qual(std::string& s, const uint8_t* seq, size_t L, const uint8_t* qual, size_t QL, bool forward) {
+  for (size_t i = 0; i < L; i += 2) {
+    const uint8_t a = forward ? seq[i] : COMP.t[seq[L - 1 - i]];
+    const uint8_t b = (i + 1 < L) ? (forward ? seq[i + 1] : COMP.t[seq[L - 2 - i]]) : 0;
+    s.push_back((char)((SEQ_CODE.t[a] << 4) | (i + 1 < L ? SEQ_CODE.t[b] : 0)));
+  }
+  if (QL == 0) {
+    s.append(L, (char)0xff);
+  } else {
+    for (size_t i = 0; i < L; i++) s.push_back((char)((forward ? qual[i] : qual[L - 1 - i]) - 33));
+  }
+}
+
+
+bool format_range_bam(const Ctx& c, const std::vector<int32_t>& sq_of_name, uint64_t r0, uint64_t r1, std::string& s,
+                      std::string& err) {
+  const thm_index* ix = c.ix;
+  std::vector<uint32_t> cig;
+  std::string txz;
+  for (uint64_t r = r0; r < r1; r++) {
+    const uint8_t* name = c.reads->names + c.reads->name_off[r];
+    const size_t name_len = (size_t)(c.reads->name_off[r + 1] - c.reads->name_off[r]);
+    const uint8_t* seq = c.reads->bases + c.reads->offsets[r];
+    const size_t L = (size_t)(c.reads->offsets[r + 1] - c.reads->offsets[r]);
+    const uint8_t* qual = c.reads->quals ? c.reads->quals + c.reads->offsets[r] : nullptr;
+    const size_t QL = qual ? L : 0;
+    size_t qn = name_len;
+    if (const void* sp = memchr(name, ' ', name_len)) qn = (size_t)((const uint8_t*)sp - name);
+    if (qn > 254) {
+      err = "read name longer than 254 bytes cannot be stored in BAM";
+      return false;
+    }
+    const uint64_t a0 = c.res->read_aln_off[r], a1 = c.res->read_aln_off[r + 1];
+    const uint64_t multimap = a1 - a0;
+    auto fixed = [&](int32_t ref_id, int32_t pos, uint32_t mapq, uint32_t bin, uint32_t n_cig, uint32_t flag) {
+      le32(s, (uint32_t)ref_id);
+      le32(s, (uint32_t)pos);
+      s.push_back((char)(qn + 1));
+      s.push_back((char)mapq);
+      le16(s, bin);
+      le16(s, n_cig);
+      le16(s, flag);
+      le32(s, (uint32_t)L);
+      le32(s, (uint32_t)-1);  // next refID
+      le32(s, (uint32_t)-1);  // next pos
+      le32(s, 0);             // tlen
+      s.append((const char*)name, qn);
+      s.push_back('\0');
+    };
+    auto close_record = [&](size_t at) {
+      const uint32_t bs = (uint32_t)(s.size() - at - 4);
+      s[at] = (char)(bs & 0xff);
+      s[at + 1] = (char)((bs >> 8) & 0xff);
+      s[at + 2] = (char)((bs >> 16) & 0xff);
+      s[at + 3] = (char)((bs >> 24) & 0xff);
+    };
+    if (multimap == 0) {
+      const size_t at = s.size();
+      le32(s, 0);
+      fixed(-1, -1, 255, 4680, 0, 4);
+      bam_seq_qual(s, seq, L, qual, QL, true);
+      close_record(at);
+      continue;
+    }
+    for (uint64_t a = a0; a < a1; a++) {
+      const thm_aln& al = c.res->alns[a];
+      if (al.ref_id >= ix->refs.size() || al.ops_off + al.ops_len > c.res->n_op_bytes) {
+        err = "alignment record out of range";
+        return false;
+      }
+      const thm_ref& ref = ix->refs[al.ref_id];
+      OpCounts cnt;
+      uint64_t ref_len = 0;
+      if (!bam_cigar(cig, c.res->ops + al.ops_off, al.ops_len, &cnt, ref_len) || cig.size() > 0xffff) {
+        err = "malformed op stream";
+        return false;
+      }
+      const int64_t pos = (int64_t)al.ystart;
+      const size_t at = s.size();
+      le32(s, 0);
+      fixed(sq_of_name[ref.name_id], (int32_t)pos, multimapq(multimap), reg2bin(pos, pos + (int64_t)std::max<uint64_t>(ref_len, 1)),
+            (uint32_t)cig.size(), (al.strand ? 0u : 16u) | (al.primary ? 0u : 256u));
+      for (uint32_t w : cig) le32(s, w);
+      bam_seq_qual(s, seq, L, qual, QL, al.strand != 0);
+      bam_int_tag(s, "AS", al.score);
+      bam_int_tag(s, "NH", (int64_t)multimap);
+      bam_int_tag(s, "HI", (int64_t)(a - a0 + 1));
+      bam_int_tag(s, "nM", (int64_t)cnt.n_subst);
+      if (al.aln_type == THM_ALN_EXONIC) {
+        const uint32_t t = al.tx_or_gene_idx;
+        if (t >= ix->txs.size() || al.tx_ops_off + al.tx_ops_len > c.res->n_op_bytes) {
+          err = "transcript alignment out of range";
+          return false;
+        }
+        const uint32_t g = ix->txs[t].gene_idx;
+        txz = ix->tx_ids[t];
+        txz += ",+";
+        put_u64(txz, al.tx_ystart);
+        txz.push_back(',');
+        if (!put_cigar(txz, c.res->ops + al.tx_ops_off, al.tx_ops_len, nullptr)) {
+          err = "malformed transcript op stream";
+          return false;
+        }
+        bam_str_tag(s, "TX", txz);
+        bam_str_tag(s, "GX", ix->gene_ids[g]);
+        bam_str_tag(s, "GN", ix->gene_names[g]);
+        s.append("REAE", 4);
+      } else if (al.aln_type == THM_ALN_INTRONIC) {
+        const uint32_t g = al.tx_or_gene_idx;
+        if (g >= ix->gene_ids.size()) {
+          err = "gene index out of range";
+          return false;
+        }
+        bam_str_tag(s, "GX", ix->gene_ids[g]);
+        bam_str_tag(s, "GN", ix->gene_names[g]);
+        s.append("REAN", 4);
+      } else {
+        s.append("REAI", 4);
+      }
+      close_record(at);
+    }
+  }
+  return true;
+}
+
+// BGZF: a series of gzip members of at most 64 KiB, each with a BC extra field giving its size
+bool bgzf_compress(const char* p, size_t n, std::string& out) {
+  constexpr size_t BLOCK = 0xff00;
+  std::vector<unsigned char> buf(compressBound(BLOCK) + 64);
+  for (size_t off = 0; off < n || (n == 0 && off == 0); off += BLOCK) {
+    const size_t len = std::min(BLOCK, n - off);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = (Bytef*)(p + off);
+    zs.avail_in = (uInt)len;
+    zs.next_out = buf.data();
+    zs.avail_out = (uInt)buf.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    const size_t bsize = clen + 25;  // whole block size - 1
+    if (bsize > 0xffff) return false;
+    const unsigned char hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
+                                   (unsigned char)(bsize & 0xff), (unsigned char)(bsize >> 8)};
+    out.append((const char*)hdr, 18);
+    out.append((const char*)buf.data(), clen);
+    le32(out, (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(p + off), (uInt)len));
+    le32(out, (uint32_t)len);
+    if (n == 0) break;
+  }
+  return true;
+}
+
 }  // namespace
 
 namespace thm {
@@ -306,11 +582,22 @@ int writer_format_chunks(thm_writer* w, const thm_read_batch* reads, const thm_b
   Ctx c{w->ix, reads, res, w->format};
   std::vector<std::string> errs(T);
   std::vector<char> ok(T, 1);
+  if (w->format == THM_FMT_BAM) w->raw.resize(std::max<size_t>(w->raw.size(), T));
   auto work = [&](unsigned t) {
     std::string& s = w->chunk[t];
     s.clear();
     const uint64_t r0 = n * t / T, r1 = n * (t + 1) / T;
-    ok[t] = format_range(c, r0, r1, s, errs[t]) ? 1 : 0;
+    if (w->format == THM_FMT_BAM) {
+      std::string& raw = w->raw[t];
+      raw.clear();
+      ok[t] = format_range_bam(c, w->sq_of_name, r0, r1, raw, errs[t]) ? 1 : 0;
+      if (ok[t] && !raw.empty() && !bgzf_compress(raw.data(), raw.size(), s)) {
+        ok[t] = 0;
+        errs[t] = "BGZF compression failed";
+      }
+    } else {
+      ok[t] = format_range(c, r0, r1, s, errs[t]) ? 1 : 0;
+    }
   };
   if (T == 1) {
     work(0);
@@ -334,8 +621,7 @@ int32_t thm_writer_create(const thm_index* ix, int32_t format, uint32_t n_thread
   if (!out) return THM_ERR_INVALID_ARG;
   *out = nullptr;
   if (!ix) return THM_ERR_INVALID_ARG;
-  if (format == THM_FMT_BAM) return fail(THM_ERR_UNSUPPORTED, "BAM output is not built; write SAM and convert");
-  if (format != THM_FMT_SAM && format != THM_FMT_PAF) return THM_ERR_INVALID_ARG;
+  if (format != THM_FMT_SAM && format != THM_FMT_PAF && format != THM_FMT_BAM) return THM_ERR_INVALID_ARG;
   if (ix->contig_names.empty() || ix->tx_ids.size() != ix->txs.size() || ix->gene_ids.size() != ix->genes.size())
     return fail(THM_ERR_INVALID_ARG, "the writer needs contig / transcript / gene names: thm_index_set_names or thm_index_create_from_files");
   thm_writer* w = new thm_writer();
@@ -343,16 +629,44 @@ int32_t thm_writer_create(const thm_index* ix, int32_t format, uint32_t n_thread
   w->format = format;
   unsigned t = n_threads ? n_threads : std::min(16u, std::thread::hardware_concurrency());
   w->n_threads = std::max(1u, std::min(t, 32u));
-  if (format == THM_FMT_SAM) {
+  if (format == THM_FMT_SAM || format == THM_FMT_BAM) {
     // build_sam_header (:256-276): the reference sequences are collected into a map keyed by name,
     // so the forward and reverse Ref of a contig share one @SQ line (first-seen order)
-    std::vector<char> seen(ix->contig_names.size(), 0);
+    std::vector<std::pair<std::string, uint64_t>> sq;
+    w->sq_of_name.assign(ix->contig_names.size(), -1);
     for (const thm_ref& r : ix->refs) {
-      if (seen[r.name_id]) continue;
-      seen[r.name_id] = 1;
-      w->header += "@SQ\tSN:" + ix->contig_names[r.name_id] + "\tLN:" + std::to_string(r.len) + "\n";
+      if (w->sq_of_name[r.name_id] >= 0) continue;
+      int32_t k = -1;
+      for (size_t i = 0; i < sq.size(); i++)
+        if (sq[i].first == ix->contig_names[r.name_id]) k = (int32_t)i;  // same name under another id: same @SQ
+      if (k < 0) {
+        k = (int32_t)sq.size();
+        sq.emplace_back(ix->contig_names[r.name_id], r.len);
+      }
+      w->sq_of_name[r.name_id] = k;
     }
-    w->header += "@PG\tID:thermite\n";
+    std::string text;
+    for (const auto& q : sq) text += "@SQ\tSN:" + q.first + "\tLN:" + std::to_string(q.second) + "\n";
+    text += "@PG\tID:thermite\n";
+    if (format == THM_FMT_SAM) {
+      w->header = text;
+    } else {
+      // bam::Writer::write_header + write_reference_sequences, src/aligner.rs:41-46
+      std::string raw("BAM\1", 4);
+      le32(raw, (uint32_t)text.size());
+      raw += text;
+      le32(raw, (uint32_t)sq.size());
+      for (const auto& q : sq) {
+        le32(raw, (uint32_t)q.first.size() + 1);
+        raw += q.first;
+        raw.push_back('\0');
+        le32(raw, (uint32_t)q.second);
+      }
+      if (!bgzf_compress(raw.data(), raw.size(), w->header) || !bgzf_compress(nullptr, 0, w->trailer)) {
+        delete w;
+        return fail(THM_ERR_INTERNAL, "BGZF compression failed");
+      }
+    }
   }
   *out = w;
   return THM_OK;
@@ -364,6 +678,13 @@ int32_t thm_writer_header(thm_writer* w, thm_text* out) {
   if (!w || !out) return THM_ERR_INVALID_ARG;
   out->data = (const uint8_t*)w->header.data();
   out->len = w->header.size();
+  return THM_OK;
+}
+
+int32_t thm_writer_trailer(thm_writer* w, thm_text* out) {
+  if (!w || !out) return THM_ERR_INVALID_ARG;
+  out->data = (const uint8_t*)w->trailer.data();
+  out->len = w->trailer.size();
   return THM_OK;
 }
 
