@@ -293,6 +293,20 @@ int32_t thm_counters_get(thm_aligner*, uint64_t out[THM_N_COUNTERS]);
 int32_t thm_counters_reset(thm_aligner*);
 /* device pointer to the same THM_N_COUNTERS u64 (for an RCCL all-reduce) */
 void* thm_counters_device_ptr(thm_aligner*);
+/* The one collective of the multi-GPU path (one process per GPU, reads sharded,
+ * index replicated): in-place sum over all ranks of the counter vector, RCCL
+ * all-reduce on the aligner's stream, synchronous on return; afterwards
+ * thm_counters_get returns the job-wide totals on every rank.  The communicator
+ * is an RCCL communicator: rank 0 calls thm_comm_unique_id and hands the 128
+ * bytes to the other ranks by any means (the reference has no multi-process
+ * mode; a torch.distributed host can equally all-reduce thm_counters_device_ptr). */
+#define THM_COMM_ID_BYTES 128
+typedef struct thm_comm thm_comm;
+int32_t thm_comm_unique_id(uint8_t out[THM_COMM_ID_BYTES]);
+int32_t thm_comm_create(const uint8_t id[THM_COMM_ID_BYTES], int32_t nranks, int32_t rank, int32_t device_id,
+                        thm_comm** out);
+void thm_comm_free(thm_comm*);
+int32_t thm_counters_allreduce(thm_aligner*, thm_comm*);
 /* milliseconds per stage of the last thm_batch_run (after thm_batch_sync) */
 int32_t thm_timings_get(thm_aligner*, float out[THM_N_TIMINGS]);
 

@@ -101,7 +101,7 @@ ABI_SYMBOLS = [
     "thm_aligner_set_opts", "thm_aligner_stream", "thm_align_batch", "thm_batch_upload", "thm_batch_run",
     "thm_batch_sync", "thm_batch_fetch", "thm_smems_batch", "thm_swg_extend_batch", "thm_counters_get",
     "thm_counters_reset", "thm_counters_device_ptr", "thm_timings_get", "thm_version", "thm_device_count",
-    "thm_aligner_index",
+    "thm_aligner_index", "thm_comm_unique_id", "thm_comm_create", "thm_comm_free", "thm_counters_allreduce",
 ]
 # every symbol include/thermite_io.h declares
 IO_ABI_SYMBOLS = [
@@ -168,6 +168,13 @@ def lib():
     L.thm_device_count.restype = i32
     L.thm_aligner_index.restype = vp
     L.thm_aligner_index.argtypes = [vp]
+    L.thm_comm_unique_id.restype = i32
+    L.thm_comm_unique_id.argtypes = [vp]
+    L.thm_comm_create.restype = i32
+    L.thm_comm_create.argtypes = [vp, i32, i32, i32, vp]
+    L.thm_comm_free.argtypes = [vp]
+    L.thm_counters_allreduce.restype = i32
+    L.thm_counters_allreduce.argtypes = [vp, vp]
     # ---- include/thermite_io.h ----
     cp = C.c_char_p
     L.thm_index_create_from_files.restype = i32
@@ -455,6 +462,10 @@ class Aligner:
     def reset_counters(self):
         self._chk(lib().thm_counters_reset(self.h))
 
+    def counters_allreduce(self, comm):
+        """sum the device counters over all ranks of `comm` (RCCL), in place"""
+        self._chk(lib().thm_counters_allreduce(self.h, comm.h))
+
     def counters_device_ptr(self):
         return lib().thm_counters_device_ptr(self.h)
 
@@ -477,6 +488,34 @@ class Aligner:
     def close(self):
         if getattr(self, "h", None):
             lib().thm_aligner_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def comm_unique_id():
+    out = np.zeros(128, np.uint8)
+    rc = lib().thm_comm_unique_id(_ptr(out))
+    if rc != 0:
+        raise ThermiteError(rc, _last_error())
+    return out
+
+
+class Comm:
+    """thm_comm: RCCL communicator for the counter all-reduce (one rank per GPU)."""
+
+    def __init__(self, unique_id, nranks, rank, device=0):
+        uid = np.ascontiguousarray(unique_id, np.uint8)
+        h = C.c_void_p()
+        rc = lib().thm_comm_create(_ptr(uid), nranks, rank, device, C.byref(h))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().thm_comm_free(self.h)
             self.h = None
 
     def __del__(self):
