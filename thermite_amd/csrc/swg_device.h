@@ -66,6 +66,32 @@ __device__ __forceinline__ int wave_excl_max_scan(int v) { return wave_incl_max_
 __device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_incl_max_scan(v), 63); }
 __device__ __forceinline__ int wave_min(int v) { return -wave_max(-v); }
 __device__ __forceinline__ int bcast_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// one v_cmp writing an SGPR pair (no 0/1 round trip through a VGPR)
+__device__ __forceinline__ unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Pins a wave-uniform value to scalar registers and hides its origin from the optimiser, which
+// otherwise folds `vote(a) & mask` back into a per-lane AND (a 0/1 round trip through a VGPR).
+__device__ __forceinline__ unsigned long long sgpr64(unsigned long long v) {
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  asm("" : "+s"(lo), "+s"(hi));
+  return ((unsigned long long)hi << 32) | lo;
+}
+// (v > t) & mask and (v >= t) & mask as lane masks: one compare into an SGPR pair and one scalar AND
+// (written out because the optimiser turns `vote(v > t) & mask` into a per-lane AND plus a re-vote)
+__device__ __forceinline__ unsigned long long mask_gt(int v, int t, unsigned long long mask) {
+  unsigned long long m;
+  asm("v_cmp_gt_i32_e64 %0, %1, %2\n\ts_and_b64 %0, %0, %3" : "=&s"(m) : "v"(v), "s"(t), "s"(mask) : "scc");
+  return m;
+}
+__device__ __forceinline__ unsigned long long mask_ge(int v, int t, unsigned long long mask) {
+  unsigned long long m;
+  asm("v_cmp_ge_i32_e64 %0, %1, %2\n\ts_and_b64 %0, %0, %3" : "=&s"(m) : "v"(v), "s"(t), "s"(mask) : "scc");
+  return m;
+}
+__device__ __forceinline__ int sgpr32(int v) {
+  v = __builtin_amdgcn_readfirstlane(v);
+  asm("" : "+s"(v));
+  return v;
+}
 
 // Load through the constant address space: with a wave-uniform address this
 // becomes an s_load (scalar cache, result in SGPRs, no EXEC games in the control
@@ -188,12 +214,16 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
   // Every rise is by exactly +1, so the first cell attaining the final maximum lies in the
   // last column that raised it, at the lowest improving row of that column.
   int run_max = 0;
-  int best_j = 0, best_top = 0;
+  int best_j = 0;
   unsigned long long best_mask[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; c++) best_mask[c] = 0;
   bool finished = false;
   unsigned long long* tr = trace + (size_t)CPL * 2;  // column 1
+  // The counters (cells, columns, last column with cells) are derived after the walk from the
+  // last column visited, not maintained per column.
+  int last_j = 0;          // last column that computed cells
+  bool empty_col = false;  // phase 2 ended on a column whose row range was empty
 
   // ---------------- phase 1: band rows 0..w-1 (reference :75-113) ----------------
   // Per-lane constants: slot index b, R offset go + b*ge, and -b*ge for the scan key.
@@ -202,12 +232,14 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
   {
     int xc[CPL];
     bool valid[CPL];
+    unsigned long long vmask[CPL];  // lanes whose slot holds a cell: masks are combined on the scalar unit
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
       const int b = lane * CPL + c;
-      const int xv = (int)xs[min(max(b - 1, 0), xlen - 1) * dx];
+      // slot 0 (row 0) has no diagonal and slots past |x| hold no cell: their x byte is a don't-care
+      xc[c] = (int)xs[min(max(b - 1, 0), xlen - 1) * dx];
       valid[c] = b < rows1;
-      xc[c] = (b >= 1 && valid[c]) ? xv : 256;
+      vmask[c] = vote(valid[c]);
     }
     // the y character of the next column is fetched one column ahead, so that the LDS
     // latency is off the column-to-column critical path
@@ -218,17 +250,20 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
       yp += dy;
       yc_next = (int)*yp;  // one past the last column at most: still inside the staged window / LDS
       int d[CPL], Cn[CPL], key[CPL];
-      const int d_in = wave_shr1(Dv[CPL - 1], MIN_SCORE);  // D[b-1] of the previous column for register 0
+      unsigned long long meq[CPL];
+      const int d_in = wave_shr1(Dv[CPL - 1], Dv[CPL - 1]);  // D[b-1] of the previous column for register 0 (lane 0: unused, slot 0 has no diagonal)
       int lane_tot = NEG;
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
         Cn[c] = max(Cv[c], Dv[c] + go) + ge;
         const int dprev = (c == 0) ? d_in : Dv[c - 1];
-        d[c] = (b == 0) ? MIN_SCORE : dprev + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);
+        const bool eq = xc[c] == yc;
+        meq[c] = vote(eq);
+        d[c] = (b == 0) ? MIN_SCORE : dprev + (eq ? MATCH_SCORE : MISMATCH_SCORE);
         const int dp = max(d[c], Cn[c]);
         key[c] = valid[c] ? dp - b * ge : NEG;
-        lane_tot = max(lane_tot, key[c]);
+        lane_tot = (c == 0) ? key[c] : max(lane_tot, key[c]);
       }
       int run = wave_excl_max_scan_fast(lane_tot);
       unsigned long long m_imp = 0, m_alive = 0, m_c[CPL];
@@ -240,8 +275,8 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         run = max(run, key[c]);
         const int Dn = max(max(d[c], Cn[c]), R);
         // direction bits (Match 0, Subst 1, Del 2, Ins 3; priority diag > Del > Ins, reference :226-240)
-        const unsigned long long hi = __ballot(Dn != d[c]);
-        const unsigned long long lo = (~hi & ~__ballot(xc[c] == yc)) | (hi & __ballot(Dn != Cn[c]));
+        const unsigned long long hi = vote(Dn != d[c]);
+        const unsigned long long lo = (~hi & ~vote(xc[c] == yc)) | (hi & vote(Dn != Cn[c]));
 #ifndef THM_EXP_NOTRACE
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
@@ -250,24 +285,21 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
 #else
         if (lo == 0x123456789ull && hi == 0x3ull && lane == 0) tr[0] = lo;
 #endif
-        m_c[c] = __ballot(valid[c] && Dn > run_max);
+        m_c[c] = mask_gt(Dn, run_max, vmask[c]);
         m_imp |= m_c[c];
-        m_alive |= __ballot(valid[c] && (Dn - b > alive_floor));
-        Dv[c] = valid[c] ? Dn : Dv[c];
-        Cv[c] = valid[c] ? Cn[c] : Cv[c];
+        m_alive |= mask_gt(Dn - b, alive_floor, vmask[c]);
+        Dv[c] = Dn;  // slots without a cell hold don't-care values: a cell only ever reads slots that held cells
+        Cv[c] = Cn[c];
       }
       tr += CPL * 2;
-      res.cells += (unsigned)rows1;
-      res.cols += 1;
-      res.jmax = j;
+      last_j = j;
       const bool imp = m_imp != 0ull;
       if (imp) {
         best_j = j;
-        best_top = 0;
 #pragma unroll
         for (int c = 0; c < CPL; c++) best_mask[c] = m_c[c];
       }
-      run_max = bcast_first(run_max + (imp ? MATCH_SCORE : 0));
+      run_max += imp ? MATCH_SCORE : 0;  // wave-uniform: the compares above take it as a scalar operand
       // reference :110: with x_drop >= band_width the X-drop test cannot fire in
       // phase 1; the early exit is ours (see above).
       // (An improving lane is alive by construction.)
@@ -298,18 +330,19 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
     }
     for (int j = bw + 1; j <= ylen; j++) {
       const int top = j - bw;
-      res.cols += 1;
       if (top > xlen) {  // empty row range: band_max = MIN -> X-drop (reference :117-153)
         res.broke = true;
+        empty_col = true;
         break;
       }
-      res.jmax = j;
+      last_j = j;
       const int nvalid = min(w, xlen + 1 - top);  // slots b < nvalid hold a cell
       const int yc = yc_next;
       yp += dy;
       yc_next = (int)*yp;
       int d[CPL], Cn[CPL], key[CPL], xc[CPL], base[CPL];
       bool valid[CPL];
+      unsigned long long meq[CPL], vmask[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; c++) base[c] = max(Cv[c], Dv[c] + go) + ge;
       const int c_in = wave_shl1(base[0], MIN_SCORE);  // slot b+1 of the previous column for the last register
@@ -318,15 +351,18 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
       for (int c = 0; c < CPL; c++) {
         const int b = lane * CPL + c;
         valid[c] = b < nvalid;
-        xc[c] = valid[c] ? xv_next[c] : 256;
+        vmask[c] = vote(valid[c]);
+        xc[c] = xv_next[c];  // beyond |x| the byte is arbitrary: it only feeds slots without a cell
         xp[c] += dx;
         xv_next[c] = (int)*xp[c];
         const int cnext = (c == CPL - 1) ? c_in : base[c + 1];
         Cn[c] = last_slot[c] ? MIN_SCORE : cnext;
-        d[c] = Dv[c] + ((xc[c] == yc) ? MATCH_SCORE : MISMATCH_SCORE);
+        const bool eq = xc[c] == yc;
+        meq[c] = vote(eq);
+        d[c] = Dv[c] + (eq ? MATCH_SCORE : MISMATCH_SCORE);
         const int dp = max(d[c], Cn[c]);
         key[c] = valid[c] ? dp - b * ge : NEG;
-        lane_tot = max(lane_tot, key[c]);
+        lane_tot = (c == 0) ? key[c] : max(lane_tot, key[c]);
       }
       int run = wave_excl_max_scan_fast(lane_tot);
       unsigned long long m_imp = 0, m_alive = 0, m_x = 0, m_c[CPL];
@@ -338,8 +374,8 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         const int R = run + (go + b * ge);
         run = max(run, key[c]);
         const int Dn = max(max(d[c], Cn[c]), R);
-        const unsigned long long hi = __ballot(Dn != d[c]);
-        const unsigned long long lo = (~hi & ~__ballot(xc[c] == yc)) | (hi & __ballot(Dn != Cn[c]));
+        const unsigned long long hi = vote(Dn != d[c]);
+        const unsigned long long lo = (~hi & ~vote(xc[c] == yc)) | (hi & vote(Dn != Cn[c]));
 #ifndef THM_EXP_NOTRACE
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
@@ -348,23 +384,21 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
 #else
         if (lo == 0x123456789ull && hi == 0x3ull && lane == 0) tr[0] = lo;
 #endif
-        m_c[c] = __ballot(valid[c] && Dn > run_max);
+        m_c[c] = mask_gt(Dn, run_max, vmask[c]);
         m_imp |= m_c[c];
-        m_x |= __ballot(valid[c] && Dn >= xfloor);
-        m_alive |= __ballot(valid[c] && (Dn - b > alive_floor));
-        Dv[c] = valid[c] ? Dn : Dv[c];
+        m_x |= mask_ge(Dn, xfloor, vmask[c]);
+        m_alive |= mask_gt(Dn - b, alive_floor, vmask[c]);
+        Dv[c] = Dn;
         Cv[c] = Cn[c];
       }
       tr += CPL * 2;
-      res.cells += (unsigned)nvalid;
       const bool imp = m_imp != 0ull;
       if (imp) {
         best_j = j;
-        best_top = top;
 #pragma unroll
         for (int c = 0; c < CPL; c++) best_mask[c] = m_c[c];
       }
-      run_max = bcast_first(run_max + (imp ? MATCH_SCORE : 0));
+      run_max += imp ? MATCH_SCORE : 0;  // wave-uniform: the compares above take it as a scalar operand
       // stop: reference :151 (band_max < max_score - x_drop) or our early exit; an improving
       // column equals the new maximum, so neither applies to it
       if (!imp && (m_x == 0ull || m_alive == 0ull)) {
@@ -374,6 +408,26 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
     }
   }
 
+  // ---------------- counters ----------------
+  {
+    res.jmax = last_j;
+    res.cols = (unsigned)last_j + (empty_col ? 1u : 0u);
+    const int n1 = min(last_j, p1_end);  // phase-1 columns: rows1 cells each
+    unsigned cells = (unsigned)n1 * (unsigned)rows1;
+    if (last_j > p1_end) {
+      // phase-2 column with top = j - bw holds min(w, |x| + 1 - top) cells, top = 1 .. t1
+      const int t1 = last_j - bw;
+      const int tfull = min(t1, xlen + 1 - w);  // tops up to here hold w cells
+      if (tfull >= 1) cells += (unsigned)tfull * (unsigned)w;
+      const int ta = max(tfull, 0) + 1;  // first top of the shrinking part
+      if (t1 >= ta) {
+        const int hi_cells = xlen + 1 - ta, lo_cells = xlen + 1 - t1;
+        cells += (unsigned)((hi_cells + lo_cells) * (t1 - ta + 1) / 2);
+      }
+    }
+    res.cells = cells;
+  }
+
   // ---------------- first (j, i) attaining the maximum ----------------
   if (run_max > 0) {
     int bmin = 64 * CPL;
@@ -381,7 +435,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
     for (int c = 0; c < CPL; c++)
       if (best_mask[c]) bmin = min(bmin, (int)__builtin_ctzll(best_mask[c]) * CPL + c);
     res.score = run_max;
-    res.xend = best_top + bmin;
+    res.xend = max(best_j - bw, 0) + bmin;  // top of the band in column best_j
     res.yend = best_j;
   }
   return res;
