@@ -258,7 +258,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         const int b = lane * CPL + c;
         Cn[c] = max(Cv[c], Dv[c] + go) + ge;
         const int dprev = (c == 0) ? d_in : Dv[c - 1];
-        const bool eq = xc[c] == yc;
+        const bool eq = (uint8_t)xc[c] == (uint8_t)yc;
         meq[c] = vote(eq);
         d[c] = (b == 0) ? MIN_SCORE : dprev + (eq ? MATCH_SCORE : MISMATCH_SCORE);
         const int dp = max(d[c], Cn[c]);
@@ -276,7 +276,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         const int Dn = max(max(d[c], Cn[c]), R);
         // direction bits (Match 0, Subst 1, Del 2, Ins 3; priority diag > Del > Ins, reference :226-240)
         const unsigned long long hi = vote(Dn != d[c]);
-        const unsigned long long lo = (~hi & ~vote(xc[c] == yc)) | (hi & vote(Dn != Cn[c]));
+        const unsigned long long lo = (~hi & ~meq[c]) | (hi & vote(Dn != Cn[c]));
 #ifndef THM_EXP_NOTRACE
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
@@ -357,7 +357,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         xv_next[c] = (int)*xp[c];
         const int cnext = (c == CPL - 1) ? c_in : base[c + 1];
         Cn[c] = last_slot[c] ? MIN_SCORE : cnext;
-        const bool eq = xc[c] == yc;
+        const bool eq = (uint8_t)xc[c] == (uint8_t)yc;
         meq[c] = vote(eq);
         d[c] = Dv[c] + (eq ? MATCH_SCORE : MISMATCH_SCORE);
         const int dp = max(d[c], Cn[c]);
@@ -375,7 +375,7 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         run = max(run, key[c]);
         const int Dn = max(max(d[c], Cn[c]), R);
         const unsigned long long hi = vote(Dn != d[c]);
-        const unsigned long long lo = (~hi & ~vote(xc[c] == yc)) | (hi & vote(Dn != Cn[c]));
+        const unsigned long long lo = (~hi & ~meq[c]) | (hi & vote(Dn != Cn[c]));
 #ifndef THM_EXP_NOTRACE
         if (lane == 0) {
           tr[c * 2 + 0] = lo;
