@@ -44,7 +44,8 @@ struct RefInfo {
   bool strand;
 };
 // Index::idx_to_ref: refs.partition_point(|x| x.end_idx <= idx)
-__device__ RefInfo idx_to_ref(const DeviceIndex& ix, uint32_t idx) {
+template <class IX>
+__device__ RefInfo idx_to_ref(const IX& ix, uint32_t idx) {
   uint32_t lo = 0, hi = ix.n_refs;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -313,7 +314,8 @@ __device__ int stage_window(Wctx& c, uint8_t* dst, const uint8_t* src, int a, in
 // includes a trailing Xclip when the read is clipped on the right, which gets its
 // own loop iteration -- so an alignment that ends exactly on an exon boundary
 // still receives the intron (the edge case noted at src/txome.rs:132).
-__device__ int lift_markers(Wctx& c, const DeviceIndex& ix, const thm_tx& tx, const uint8_t* path, int n, bool trailing_clip,
+template <class IX>
+__device__ int lift_markers(Wctx& c, const IX& ix, const thm_tx& tx, const uint8_t* path, int n, bool trailing_clip,
                             int ystart, int yend, int& gx_ystart, int& gx_yend) {
   const thm_exon* ex = ix.exons + tx.exon_begin;
   const uint64_t* toff = ix.exon_txoff + tx.exon_begin;
@@ -394,7 +396,8 @@ __device__ int lift_markers(Wctx& c, const DeviceIndex& ix, const thm_tx& tx, co
 // global op pool, every lane writing its own bytes; `reverse` mirrors the whole
 // list (concat_to_chr_aln on a reverse-strand Ref, src/aligner.rs:440-447).
 // Returns the pool offset, byte count in n_bytes.
-__device__ unsigned long long emit_alignment(Wctx& c, const ExtendParams& p, const uint8_t* path, int n, int xstart, int xend,
+template <class PP>
+__device__ unsigned long long emit_alignment(Wctx& c, const PP& p, const uint8_t* path, int n, int xstart, int xend,
                                              bool reverse, int n_y, int& n_bytes) {
   const int lane = lane_id();
   const int lead = xstart, trail = c.L - xend;
@@ -446,8 +449,21 @@ __device__ unsigned long long emit_alignment(Wctx& c, const ExtendParams& p, con
   return off;
 }
 
+#ifndef THM_KARG_QUAL
+#define THM_KARG_QUAL volatile
+#endif
 template <int CPL, int MINW>
-__global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
+__global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_value) {
+  // The parameter block (about 70 dwords) is read from the kernel-argument segment where it is
+  // needed (scalar loads, THM_KARG_QUAL = volatile keeps them at their use sites) instead of being
+  // loaded at entry: the kernel is far over the scalar register budget, and every parameter that
+  // lives in a register across the hit loop is spilled to VGPR lanes and read back with v_readlane.
+#if __HIP_DEVICE_COMPILE__
+  typedef THM_KARG_QUAL const __attribute__((address_space(4))) ExtendParams KArgs;
+  KArgs& p = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  const ExtendParams& p = p_by_value;
+#endif
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
@@ -481,7 +497,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p) {
   c.prof_last = __builtin_amdgcn_s_memtime();
 #endif
 
-  const DeviceIndex& ix = p.ix;
+  auto& ix = p.ix;
   unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_type[3] = {0, 0, 0}, k_reads = 0, k_opb = 0;
   unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
 
@@ -1090,12 +1106,15 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
-  // register budget: MINW waves per SIMD (default 4; tuning knob THM_EXT_MINW = 2..6 | 8)
-  static const int minw = [] {
+  // register budget: MINW waves per SIMD.  Default 5 for the one- and two-cell-per-lane kernels
+  // (96 VGPRs with a handful of spilled ones; LDS admits 5 workgroups per CU for 91 bp reads),
+  // 4 for wider bands; tuning knob THM_EXT_MINW = 2..6 | 8.
+  static const int minw_env = [] {
     const char* e = getenv("THM_EXT_MINW");
-    const int v = e ? atoi(e) : 4;
-    return (v >= 2 && v <= 8) ? v : 4;
+    const int v = e ? atoi(e) : 0;
+    return (v >= 2 && v <= 8) ? v : 0;
   }();
+  const int minw = minw_env ? minw_env : (cpl <= 2 ? 5 : 4);
 #define THM_EXT_CASE(C)                                  \
   case C:                                                \
     if (minw == 4) return go(dev::extend_kernel<C, 4>);  \
