@@ -231,29 +231,69 @@ __global__ void sanitize_kernel(const uint8_t* in, uint8_t* out, uint64_t n, uin
     out[i] = 0;
 }
 
-// Matching statistics, one thread per (read, position), in two launches.
-// FIRST: position 0 of every read.  REST: positions >= 1, skipped when the match
-// from position 0 already reaches the end of the read: ends are non-decreasing in
-// the start position, so no later start can open a new SMEM (end[i] > end[i-1] is
-// impossible once end == L) -- the common case for error-free reads, which then
-// cost one probe instead of L-k+1.
-template <bool FIRST>
+// Matching statistics, one thread per (read, position), in three launches that probe
+// fewer and fewer positions.  E[i] = i + MS[i], the end of the longest match from i,
+// never decreases with i (MS[i+1] >= MS[i] - 1), and a position starts an SMEM iff
+// MS[i] >= k and E[i] > E[i-1]:
+//   STAGE 0: position 0 of every read.  If that match spans the read (the common case
+//            for error-free reads) no later position can start an SMEM and the other
+//            stages skip the read: one probe instead of L-k+1.
+//   STAGE 1: every PROBE_STRIDE-th position and the last one.
+//   STAGE 2: the positions in between.  When both neighbours on the stride grid have
+//            MS >= k and the same end, every position between them has that end too
+//            (and MS >= k), so nothing starts there: the thread records the end without
+//            probing.  Only the grid cells around a jump of E (a mismatch) are probed.
+constexpr int PROBE_STRIDE = 8;
+
+template <int STAGE>
 __global__ __launch_bounds__(256) void seed_probe_kernel(SeedParams p) {
   const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint32_t P = p.pos_per_read;
-  const uint64_t read = FIRST ? tid : tid / P;
+  const uint32_t G = (P + PROBE_STRIDE - 1) / PROBE_STRIDE + 1;  // stage-1 slots per read: the grid and the last position
+  const uint64_t read = STAGE == 0 ? tid : (STAGE == 1 ? tid / G : tid / P);
   if (read >= p.reads.n_reads) return;
-  const int pos = FIRST ? 0 : (int)(tid - read * P);
-  const uint64_t item = read * P + (uint64_t)pos;
-  if (!FIRST && pos == 0) return;
   const uint64_t r0 = p.reads.offsets[read];
   const int L = (int)(p.reads.offsets[read + 1] - r0);
   const int k = (int)p.min_seed_len;
+  const int npos = max(L - k + 1, 0);  // positions of this read where a seed fits
+  int pos;
+  if (STAGE == 0) {
+    pos = 0;
+  } else if (STAGE == 1) {
+    const int g = (int)(tid - read * G);
+    pos = (g + 1 == (int)G) ? npos - 1 : g * PROBE_STRIDE;
+    // position 0 belongs to stage 0; the last position is probed once (by the extra slot)
+    if (pos <= 0 || pos >= npos || (g + 1 != (int)G && pos == npos - 1)) return;
+  } else {
+    pos = (int)(tid - read * P);
+    if (pos % PROBE_STRIDE == 0 || pos >= npos - 1) {
+      if (pos >= npos && pos < (int)P) {  // past the last seed position of a shorter read: nothing matches
+        const uint64_t item = read * P + (uint64_t)pos;
+        p.ms_end[item] = 0;
+        p.ms_lo[item] = 0;
+        p.ms_hi[item] = 0;
+      }
+      return;
+    }
+  }
+  const uint64_t item = read * P + (uint64_t)pos;
   int d = 0;
   uint32_t lo = 0, hi = 0;
-  const bool covered = !FIRST && L > 0 && (int)p.ms_end[read * P] == L;
-  if (!covered && pos + k <= L) ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
-  p.ms_end[item] = (uint16_t)((d >= k) ? pos + d : 0);
+  bool probe = pos + k <= L;
+  int known_end = 0;
+  if (STAGE != 0) {
+    if (L > 0 && (int)p.ms_end[read * P] == L) probe = false;  // covered by the match from position 0
+    if (STAGE == 2 && probe) {
+      const int a = pos - pos % PROBE_STRIDE, b = min(a + PROBE_STRIDE, npos - 1);
+      const int ea = p.ms_end[read * P + (uint64_t)a], eb = p.ms_end[read * P + (uint64_t)b];
+      if (ea != 0 && ea == eb) {  // same end on both sides: same end here, nothing starts in (a, b]
+        probe = false;
+        known_end = ea;
+      }
+    }
+  }
+  if (probe) ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
+  p.ms_end[item] = (uint16_t)(known_end ? known_end : ((d >= k) ? pos + d : 0));
   p.ms_lo[item] = lo;
   p.ms_hi[item] = hi;
 }
@@ -439,10 +479,14 @@ hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t
 hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s) {
   const uint64_t items = p.reads.n_reads * (uint64_t)p.pos_per_read;
   if (items) {
-    hipLaunchKernelGGL(dev::seed_probe_kernel<true>, dim3((unsigned)((p.reads.n_reads + 255) / 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dev::seed_probe_kernel<0>, dim3((unsigned)((p.reads.n_reads + 255) / 256)), dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dev::seed_probe_kernel<false>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p);
+    const uint64_t grid_items = p.reads.n_reads * (uint64_t)((p.pos_per_read + dev::PROBE_STRIDE - 1) / dev::PROBE_STRIDE + 1);
+    hipLaunchKernelGGL(dev::seed_probe_kernel<1>, dim3((unsigned)((grid_items + 255) / 256)), dim3(256), 0, s, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dev::seed_probe_kernel<2>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
