@@ -97,7 +97,7 @@ struct thm_aligner {
   uint32_t max_read_len = 0;
   bool uploaded = false;
   // seeds
-  DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp, s_ms_end, s_ms_lo, s_ms_hi;
+  DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp, s_ms_end, s_ms_lo, s_ms_hi, s_work_reads, s_work_cells, s_work_counts;
   uint64_t smem_cap = 0;
   // extension
   DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off;

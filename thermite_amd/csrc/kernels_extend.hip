@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
   constexpr unsigned QCHUNK = 4;  // reads taken from the work queue per atomic
   unsigned q_next = 0, q_end = 0;
   for (;;) {
-    if (q_next == q_end) {
+    if (q_next == q_end) {  // (a fixed interleaved deal of the reads is slower here: the cost per read varies too much)
       unsigned g = 0;
       if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
       g = (unsigned)bcast_first((int)g);

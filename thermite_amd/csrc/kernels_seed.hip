@@ -231,69 +231,180 @@ __global__ void sanitize_kernel(const uint8_t* in, uint8_t* out, uint64_t n, uin
     out[i] = 0;
 }
 
-// Matching statistics, one thread per (read, position), in three launches that probe
-// fewer and fewer positions.  E[i] = i + MS[i], the end of the longest match from i,
-// never decreases with i (MS[i+1] >= MS[i] - 1), and a position starts an SMEM iff
-// MS[i] >= k and E[i] > E[i-1]:
-//   STAGE 0: position 0 of every read.  If that match spans the read (the common case
-//            for error-free reads) no later position can start an SMEM and the other
-//            stages skip the read: one probe instead of L-k+1.
-//   STAGE 1: every PROBE_STRIDE-th position and the last one.
-//   STAGE 2: the positions in between.  When both neighbours on the stride grid have
-//            MS >= k and the same end, every position between them has that end too
-//            (and MS >= k), so nothing starts there: the thread records the end without
-//            probing.  Only the grid cells around a jump of E (a mismatch) are probed.
+// Matching statistics by probing fewer and fewer positions.  E[i] = i + MS[i], the end of
+// the longest match from i, never decreases with i (MS[i+1] >= MS[i] - 1), and a position
+// starts an SMEM iff MS[i] >= k and E[i] > E[i-1]:
+//   seed_first_kernel  position 0 of every read.  If that match spans the read (the common
+//                      case for error-free reads) it is the read's only SMEM: it is emitted
+//                      here and the read leaves the seed stage after one probe.  The other
+//                      reads go on a work list.
+//   seed_grid_kernel   every PROBE_STRIDE-th position and the last one, for listed reads.
+//   seed_cells_kernel  one thread per grid cell (the positions between two grid points): when
+//                      both ends of the cell have MS >= k and the same end, every position
+//                      inside has that end too (and MS >= k), so nothing starts there and
+//                      the end is recorded without probing; other cells go on a work list.
+//   seed_fill_kernel   the inner positions of listed cells: the cells around a jump of E.
+// The work lists keep the probing launches dense (whole waves of real probes).
 constexpr int PROBE_STRIDE = 8;
 
-template <int STAGE>
-__global__ __launch_bounds__(256) void seed_probe_kernel(SeedParams p) {
+// append `value` to a list for every lane with `flag`: one atomic per wave
+__device__ __forceinline__ void wave_append(bool flag, unsigned long long value, unsigned long long* list,
+                                            unsigned long long* count) {
+  const unsigned long long m = __ballot(flag);
+  if (m == 0ull) return;
+  const int lane = lane_id();
+  const int leader = (int)__builtin_ctzll(m);
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(m));
+  base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)(base & 0xffffffffu), leader);
+  if (flag) list[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+// the same for a whole 256-thread workgroup: one atomic per workgroup (every thread must call it)
+__device__ __forceinline__ void block_append(bool flag, unsigned long long value, unsigned long long* list,
+                                             unsigned long long* count) {
+  __shared__ unsigned w_cnt[4];
+  __shared__ unsigned long long b_base;
+  const unsigned long long m = __ballot(flag);
+  const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+  if (lane == 0) w_cnt[wv] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned total = w_cnt[0] + w_cnt[1] + w_cnt[2] + w_cnt[3];
+    b_base = total ? atomicAdd(count, (unsigned long long)total) : 0ull;
+  }
+  __syncthreads();
+  unsigned before = 0;
+  for (int w = 0; w < wv; w++) before += w_cnt[w];
+  if (flag) list[b_base + before + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+__global__ __launch_bounds__(256) void seed_first_kernel(SeedParams p) {
+  const uint64_t read = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = lane_id();
+  const bool active = read < p.reads.n_reads;
+  const uint32_t P = p.pos_per_read;
+  const int k = (int)p.min_seed_len;
+  int d = 0, L = 0;
+  uint32_t lo = 0, hi = 0;
+  if (active) {
+    const uint64_t r0 = p.reads.offsets[read];
+    L = (int)(p.reads.offsets[read + 1] - r0);
+    if (k <= L) ms_search(p.ix, p.reads.bases + r0, L, 0, k, d, lo, hi);
+    const uint64_t item = read * P;
+    p.ms_end[item] = (uint16_t)((d >= k) ? d : 0);
+    p.ms_lo[item] = lo;
+    p.ms_hi[item] = hi;
+  }
+  const bool covered = active && d >= k && d == L;
+  // reads with more positions to look at
+  block_append(active && !covered && L - k + 1 > 1, read, p.work_reads, &p.work_counts[0]);
+  // a covered read is done: its one SMEM goes to the pool here (seed_select_kernel skips it)
+  const unsigned long long m = __ballot(covered);
+  if (m) {
+    const int leader = (int)__builtin_ctzll(m);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(p.cursor, (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)(base & 0xffffffffu), leader);
+    const bool fits = base + (unsigned long long)__popcll(m) <= p.smem_cap;
+    unsigned long long hits = 0;
+    if (covered) {
+      const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+      if (fits) {
+        Smem sm;
+        sm.lo = lo;
+        sm.hi = hi;
+        sm.qpos = 0;
+        sm.len = (uint16_t)L;
+        p.smems[slot] = sm;
+      }
+      hits = (unsigned long long)(hi - lo);
+      p.read_smem_off[read] = slot;
+      p.read_smem_cnt[read] = 1u;
+      p.read_hits[read] = hits;
+    }
+    for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
+    if (lane == leader) {
+      if (!fits) atomicExch(p.fault, 1);
+      atomicAdd(&p.counters[THM_CNT_SMEMS], (unsigned long long)__popcll(m));
+      atomicAdd(&p.counters[THM_CNT_HITS], hits);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void seed_grid_kernel(SeedParams p) {
   const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint32_t P = p.pos_per_read;
-  const uint32_t G = (P + PROBE_STRIDE - 1) / PROBE_STRIDE + 1;  // stage-1 slots per read: the grid and the last position
-  const uint64_t read = STAGE == 0 ? tid : (STAGE == 1 ? tid / G : tid / P);
-  if (read >= p.reads.n_reads) return;
+  const uint32_t G = (P + PROBE_STRIDE - 1) / PROBE_STRIDE + 1;  // slots per read: the grid and the last position
+  const uint64_t wi = tid / G;
+  if (wi >= p.work_counts[0]) return;
+  const uint64_t read = p.work_reads[wi];
+  const int g = (int)(tid - wi * G);
   const uint64_t r0 = p.reads.offsets[read];
   const int L = (int)(p.reads.offsets[read + 1] - r0);
   const int k = (int)p.min_seed_len;
-  const int npos = max(L - k + 1, 0);  // positions of this read where a seed fits
-  int pos;
-  if (STAGE == 0) {
-    pos = 0;
-  } else if (STAGE == 1) {
-    const int g = (int)(tid - read * G);
-    pos = (g + 1 == (int)G) ? npos - 1 : g * PROBE_STRIDE;
-    // position 0 belongs to stage 0; the last position is probed once (by the extra slot)
-    if (pos <= 0 || pos >= npos || (g + 1 != (int)G && pos == npos - 1)) return;
-  } else {
-    pos = (int)(tid - read * P);
-    if (pos % PROBE_STRIDE == 0 || pos >= npos - 1) {
-      if (pos >= npos && pos < (int)P) {  // past the last seed position of a shorter read: nothing matches
-        const uint64_t item = read * P + (uint64_t)pos;
-        p.ms_end[item] = 0;
-        p.ms_lo[item] = 0;
-        p.ms_hi[item] = 0;
-      }
-      return;
-    }
-  }
-  const uint64_t item = read * P + (uint64_t)pos;
+  const int npos = L - k + 1;  // > 1 for listed reads
+  const int pos = (g + 1 == (int)G) ? npos - 1 : g * PROBE_STRIDE;
+  // position 0 was probed by seed_first_kernel; the last position is probed once (by the extra slot)
+  if (pos <= 0 || pos >= npos || (g + 1 != (int)G && pos == npos - 1)) return;
   int d = 0;
   uint32_t lo = 0, hi = 0;
-  bool probe = pos + k <= L;
-  int known_end = 0;
-  if (STAGE != 0) {
-    if (L > 0 && (int)p.ms_end[read * P] == L) probe = false;  // covered by the match from position 0
-    if (STAGE == 2 && probe) {
-      const int a = pos - pos % PROBE_STRIDE, b = min(a + PROBE_STRIDE, npos - 1);
-      const int ea = p.ms_end[read * P + (uint64_t)a], eb = p.ms_end[read * P + (uint64_t)b];
-      if (ea != 0 && ea == eb) {  // same end on both sides: same end here, nothing starts in (a, b]
-        probe = false;
-        known_end = ea;
+  ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
+  const uint64_t item = read * P + (uint64_t)pos;
+  p.ms_end[item] = (uint16_t)((d >= k) ? pos + d : 0);
+  p.ms_lo[item] = lo;
+  p.ms_hi[item] = hi;
+}
+
+__global__ __launch_bounds__(256) void seed_cells_kernel(SeedParams p) {
+  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t P = p.pos_per_read;
+  const uint32_t C = (P + PROBE_STRIDE - 1) / PROBE_STRIDE;  // cells per read
+  const uint64_t wi = tid / C;
+  bool todo = false;
+  uint64_t read = 0;
+  int c = 0;
+  if (wi < p.work_counts[0]) {
+    read = p.work_reads[wi];
+    c = (int)(tid - wi * C);
+    const uint64_t r0 = p.reads.offsets[read];
+    const int L = (int)(p.reads.offsets[read + 1] - r0);
+    const int npos = L - (int)p.min_seed_len + 1;
+    const int a = c * PROBE_STRIDE, b = min(a + PROBE_STRIDE, npos - 1);
+    if (b - a > 1) {  // the cell has inner positions
+      const uint64_t item0 = read * P;
+      const int ea = p.ms_end[item0 + (uint64_t)a], eb = p.ms_end[item0 + (uint64_t)b];
+      if (ea != 0 && ea == eb) {
+        for (int q = a + 1; q < b; q++) p.ms_end[item0 + (uint64_t)q] = (uint16_t)ea;  // same end: nothing starts here
+      } else {
+        todo = true;
       }
     }
   }
-  if (probe) ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
-  p.ms_end[item] = (uint16_t)(known_end ? known_end : ((d >= k) ? pos + d : 0));
+  block_append(todo, (read << 16) | (unsigned long long)c, p.work_cells, &p.work_counts[1]);
+}
+
+__global__ __launch_bounds__(256) void seed_fill_kernel(SeedParams p) {
+  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t ci = tid / PROBE_STRIDE;
+  if (ci >= p.work_counts[1]) return;
+  const int j = (int)(tid % PROBE_STRIDE);
+  if (j == 0) return;  // the cell's left end is a grid position
+  const unsigned long long w = p.work_cells[ci];
+  const uint64_t read = w >> 16;
+  const int c = (int)(w & 0xffffu);
+  const uint32_t P = p.pos_per_read;
+  const uint64_t r0 = p.reads.offsets[read];
+  const int L = (int)(p.reads.offsets[read + 1] - r0);
+  const int k = (int)p.min_seed_len;
+  const int npos = L - k + 1;
+  const int pos = c * PROBE_STRIDE + j;
+  if (pos >= min(c * PROBE_STRIDE + PROBE_STRIDE, npos - 1)) return;
+  int d = 0;
+  uint32_t lo = 0, hi = 0;
+  ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
+  const uint64_t item = read * P + (uint64_t)pos;
+  p.ms_end[item] = (uint16_t)((d >= k) ? pos + d : 0);
   p.ms_lo[item] = lo;
   p.ms_hi[item] = hi;
 }
@@ -318,22 +429,37 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
   unsigned long long c_smems = 0, c_hits = 0;
   constexpr unsigned QCHUNK = 8;
   unsigned q_next = 0, q_end = 0;
+  // Work distribution: most reads are dealt out in fixed interleaved chunks (wave w takes chunks
+  // w, w + W, ...: no atomics), the last eighth through the atomic queue so that the waves finish
+  // together.  One hot word serves only ~88 M returning atomics per second.
+  const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+  const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
+  const unsigned n_static_chunks = (unsigned)(((unsigned long long)p.reads.n_reads * 7 / 8) / QCHUNK / n_waves) * n_waves;
+  unsigned s_chunk = wave_global;
   unsigned long long pool_off = 0;
   unsigned pool_left = 0;
   for (;;) {
     if (q_next == q_end) {
-      unsigned g = 0;
-      if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
-      g = (unsigned)bcast_first((int)g);
-      if (g >= p.reads.n_reads) break;
-      q_next = g;
-      q_end = min(g + QCHUNK, (unsigned)p.reads.n_reads);
+      if (s_chunk < n_static_chunks) {
+        q_next = s_chunk * QCHUNK;
+        q_end = q_next + QCHUNK;
+        s_chunk += n_waves;
+      } else {
+        unsigned g = 0;
+        if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
+        g = n_static_chunks * QCHUNK + (unsigned)bcast_first((int)g);
+        if (g >= p.reads.n_reads) break;
+        q_next = g;
+        q_end = min(g + QCHUNK, (unsigned)p.reads.n_reads);
+      }
     }
     const unsigned idx = q_next++;
     const uint64_t r0 = uload(&p.reads.offsets[idx]);
     const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
     const int npos = max(L - k + 1, 0);  // positions that were probed
     const uint64_t item0 = (uint64_t)idx * P;
+    // a read whose match from position 0 spans it was finished by seed_first_kernel
+    if (npos > 0 && (int)uload(&p.ms_end[item0]) == L) continue;
 #pragma unroll 1
     for (int t = lane; t < npos; t += 64) a_end[t] = p.ms_end[item0 + t];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -477,18 +603,23 @@ hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t
 }
 
 hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s) {
-  const uint64_t items = p.reads.n_reads * (uint64_t)p.pos_per_read;
-  if (items) {
-    hipLaunchKernelGGL(dev::seed_probe_kernel<0>, dim3((unsigned)((p.reads.n_reads + 255) / 256)), dim3(256), 0, s, p);
+  const uint64_t n = p.reads.n_reads;
+  if (n) {
+    const uint32_t P = p.pos_per_read;
+    const uint64_t G = (P + dev::PROBE_STRIDE - 1) / dev::PROBE_STRIDE + 1, C = (P + dev::PROBE_STRIDE - 1) / dev::PROBE_STRIDE;
+    auto blocks = [](uint64_t threads) { return dim3((unsigned)((threads + 255) / 256)); };
+    hipLaunchKernelGGL(dev::seed_first_kernel, blocks(n), dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const uint64_t grid_items = p.reads.n_reads * (uint64_t)((p.pos_per_read + dev::PROBE_STRIDE - 1) / dev::PROBE_STRIDE + 1);
-    hipLaunchKernelGGL(dev::seed_probe_kernel<1>, dim3((unsigned)((grid_items + 255) / 256)), dim3(256), 0, s, p);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dev::seed_probe_kernel<2>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (P > 1) {
+      // grids sized for the worst case; threads past the work-list counts (device memory) leave at once
+      hipLaunchKernelGGL(dev::seed_grid_kernel, blocks(n * G), dim3(256), 0, s, p);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      hipLaunchKernelGGL(dev::seed_cells_kernel, blocks(n * C), dim3(256), 0, s, p);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      hipLaunchKernelGGL(dev::seed_fill_kernel, blocks(n * C * dev::PROBE_STRIDE), dim3(256), 0, s, p);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
   }
   const size_t lds = seed_lds_bytes(p.max_read_len);
   if (lds > 48 * 1024) {

@@ -44,6 +44,9 @@ struct SeedParams {
   uint16_t* ms_end;            // [n_reads * pos_per_read] end of the longest match from this position (0: < k)
   uint32_t* ms_lo;             // its suffix-array interval
   uint32_t* ms_hi;
+  unsigned long long* work_reads;   // [n_reads] reads that need more than the probe at position 0
+  unsigned long long* work_cells;   // [n_reads * cells per read] (read << 16 | cell) of grid cells to probe
+  unsigned long long* work_counts;  // [2] list lengths, zeroed before launch
   Smem* smems;                 // pool
   uint64_t smem_cap;           // pool capacity (entries)
   unsigned long long* cursor;  // bump allocator head (entries), zeroed before launch

@@ -60,6 +60,10 @@ int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
   HIPCHK(a, a->s_ms_end.ensure(items * 2 + 64));
   HIPCHK(a, a->s_ms_lo.ensure(items * 4 + 64));
   HIPCHK(a, a->s_ms_hi.ensure(items * 4 + 64));
+  HIPCHK(a, a->s_work_reads.ensure((n + 1) * 8));
+  HIPCHK(a, a->s_work_cells.ensure((n * (uint64_t)((P + 7) / 8) + 1) * 8));
+  HIPCHK(a, a->s_work_counts.ensure(64));
+  HIPCHK(a, hipMemsetAsync(a->s_work_counts.p, 0, 64, s));
   int rc = reset_queue(a);
   if (rc != THM_OK) return rc;
   HIPCHK(a, hipMemsetAsync(a->d_cursors.p, 0, 64, s));
@@ -69,6 +73,9 @@ int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
   sp.ms_end = a->s_ms_end.as<uint16_t>();
   sp.ms_lo = a->s_ms_lo.as<uint32_t>();
   sp.ms_hi = a->s_ms_hi.as<uint32_t>();
+  sp.work_reads = a->s_work_reads.as<unsigned long long>();
+  sp.work_cells = a->s_work_cells.as<unsigned long long>();
+  sp.work_counts = a->s_work_counts.as<unsigned long long>();
   sp.reads.bases = a->r_san.as<uint8_t>();
   sp.reads.offsets = a->r_offsets.as<uint64_t>();
   sp.reads.n_reads = n;
