@@ -3,7 +3,7 @@
 FASTQ on disk -> thm_align_files -> SAM / PAF.   python tools_e2e.py [ref_len] [n_reads] [threads]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from thermite_amd import capi, synth
 
 ref_len = int(sys.argv[1]) if len(sys.argv) > 1 else 4000000

@@ -3,7 +3,7 @@
 python tools_perf.py [ref_len] [n_reads] [opts]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from thermite_amd import capi, synth
 
 ref_len = int(sys.argv[1]) if len(sys.argv) > 1 else 4000000

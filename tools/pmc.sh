@@ -5,8 +5,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/sq -o sq -- python3 $REPO/tools_perf.py ${2:-4000000} 500000 ${3:-ci} > $OUT/perf.txt 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/sq2 -o sq2 -- python3 $REPO/tools_perf.py ${2:-4000000} 500000 ${3:-ci} > $OUT/perf2.txt 2>&1 || true
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/sq -o sq -- python3 $REPO/tools/perf.py ${2:-4000000} 500000 ${3:-ci} > $OUT/perf.txt 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/sq2 -o sq2 -- python3 $REPO/tools/perf.py ${2:-4000000} 500000 ${3:-ci} > $OUT/perf2.txt 2>&1 || true
 python3 - <<PY
 import csv, collections, glob
 for d in ("sq","sq2"):

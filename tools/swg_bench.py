@@ -2,11 +2,11 @@
 """Micro-benchmark of the operator-level SWG kernel (tuning aid): columns/s of the DP alone."""
 import sys, time
 import numpy as np
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from thermite_amd import capi, refdata
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-D = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "tests", "golden", "data")
+D = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "tests", "golden", "data")
 t = refdata.load_reference(D + "/test_ref.fasta", D + "/test_ref.gtf")
 ix = capi.Index(t)
 a = capi.Aligner(ix, dict(capi.DEFAULT_OPTS, min_seed_len=3, min_aln_score=0))

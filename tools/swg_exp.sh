@@ -6,7 +6,7 @@ for v in thermite_amd exp_NOSCAN exp_NONOP exp_NOTRACE; do
   export THM_LIB=$REPO/thermite_amd/_build/lib$v.so
   OUT=$REPO/gpurun_out/swgexp_$v
   mkdir -p $OUT
-  rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/tools_swg_bench.py 200000 > $OUT/out.txt 2>&1 || { tail -5 $OUT/out.txt; exit 1; }
+  rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/tools/swg_bench.py 200000 > $OUT/out.txt 2>&1 || { tail -5 $OUT/out.txt; exit 1; }
   python3 - <<PY
 import csv
 rows=[r for r in csv.DictReader(open("$OUT/t_kernel_trace.csv")) if "swg_batch" in r["Kernel_Name"]]

@@ -6,7 +6,7 @@ for bpc in 1 2 4 8; do
   export THM_SWG_BPC=$bpc
   OUT=$REPO/gpurun_out/swgocc_$bpc
   mkdir -p $OUT
-  rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/tools_swg_bench.py 200000 > $OUT/out.txt 2>&1 || exit 1
+  rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/tools/swg_bench.py 200000 > $OUT/out.txt 2>&1 || exit 1
   python3 - <<PY
 import csv
 rows=[r for r in csv.DictReader(open("$OUT/t_kernel_trace.csv")) if "swg_batch" in r["Kernel_Name"]]

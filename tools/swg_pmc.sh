@@ -10,7 +10,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRAN
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC" \
            "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_IFETCH SQ_WAIT_IFETCH SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/s$i -o s -- python3 $REPO/tools_swg_bench.py 200000 > $OUT/out$i.txt 2>&1 || { tail -3 $OUT/out$i.txt; continue; }
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/s$i -o s -- python3 $REPO/tools/swg_bench.py 200000 > $OUT/out$i.txt 2>&1 || { tail -3 $OUT/out$i.txt; continue; }
 done
 python3 - <<PY
 import csv, collections, glob

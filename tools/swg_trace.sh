@@ -3,7 +3,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/swgtrace
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/tools_swg_bench.py 200000 > $OUT/out.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/tools/swg_bench.py 200000 > $OUT/out.txt 2>&1
 cat $OUT/out.txt | grep xlen
 python3 - <<PY
 import csv

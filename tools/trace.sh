@@ -4,6 +4,6 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/trace_$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $REPO/tools_perf.py ${2:-4000000} 500000 ${3:-ci} > $OUT/perf.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $REPO/tools/perf.py ${2:-4000000} 500000 ${3:-ci} > $OUT/perf.txt 2>&1
 cut -d, -f1-4 $OUT/t_kernel_stats.csv | head -12
 tail -3 $OUT/perf.txt
