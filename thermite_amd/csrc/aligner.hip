@@ -93,7 +93,7 @@ static int get_dev_copy(thm_aligner* a) {
 }
 
 int reset_queue(thm_aligner* a) {
-  HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, 64, a->stream));
+  HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, thm::QUEUE_BYTES, a->stream));
   HIPCHK(a, hipMemsetAsync(a->d_fault.p, 0, 64, a->stream));
   return THM_OK;
 }
@@ -146,7 +146,7 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
     return bail(fail(nullptr, THM_ERR_HIP, "hipStreamCreate failed"));
   for (auto& e : a->ev)
     if (hipEventCreate(&e) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipEventCreate failed"));
-  if (a->d_counters.ensure(THM_N_COUNTERS * 8 * 3) != hipSuccess || a->d_queue.ensure(64) != hipSuccess ||
+  if (a->d_counters.ensure(THM_N_COUNTERS * 8 * 3) != hipSuccess || a->d_queue.ensure(thm::QUEUE_BYTES) != hipSuccess ||
       a->d_fault.ensure(64) != hipSuccess || a->d_cursors.ensure(64) != hipSuccess)
     return bail(fail(nullptr, THM_ERR_OOM, "scratch allocation failed"));
   (void)hipMemsetAsync(a->d_counters.p, 0, THM_N_COUNTERS * 8 * 3, a->stream);

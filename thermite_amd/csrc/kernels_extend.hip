@@ -501,16 +501,37 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
   unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_type[3] = {0, 0, 0}, k_reads = 0, k_opb = 0;
   unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
 
-  constexpr unsigned QCHUNK = 4;  // reads taken from the work queue per atomic
+  // Reads are handed out by atomic counters, QCHUNK at a time.  Small chunks balance the waves
+  // (the cost per read varies by orders of magnitude: repeats), but one hot word serves only ~88 M
+  // returning atomics per second; so there are EXT_NQ counters on separate cache lines, each over
+  // its own contiguous share of the batch, and a wave that finds its counter exhausted moves on to
+  // the next one.
+#ifndef THM_EXT_QCHUNK
+#define THM_EXT_QCHUNK 1
+#endif
+  constexpr unsigned QCHUNK = THM_EXT_QCHUNK;
   unsigned q_next = 0, q_end = 0;
+  const unsigned n_total = (unsigned)p.reads.n_reads;
+  const unsigned q_share = (n_total + EXT_NQ - 1) / EXT_NQ;
+  unsigned my_q = (blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % EXT_NQ, q_tried = 0;
   for (;;) {
-    if (q_next == q_end) {  // (a fixed interleaved deal of the reads is slower here: the cost per read varies too much)
-      unsigned g = 0;
-      if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
-      g = (unsigned)bcast_first((int)g);
-      if (g >= p.reads.n_reads) break;
-      q_next = g;
-      q_end = min(g + QCHUNK, (unsigned)p.reads.n_reads);
+    if (q_next == q_end) {
+      bool got = false;
+      while (q_tried < EXT_NQ) {
+        unsigned g = 0;
+        if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, QCHUNK);
+        g = (unsigned)bcast_first((int)g);
+        const unsigned lo = my_q * q_share, hi = min(lo + q_share, n_total);
+        if (lo < hi && g < hi - lo) {
+          q_next = lo + g;
+          q_end = min(q_next + QCHUNK, hi);
+          got = true;
+          break;
+        }
+        my_q = (my_q + 1) % EXT_NQ;
+        q_tried++;
+      }
+      if (!got) break;
     }
     const unsigned idx = q_next++;
     const uint64_t r0 = uload(&p.reads.offsets[idx]);

@@ -95,6 +95,10 @@ struct Cand {
   uint8_t strand, aln_type, primary, pad_;
 };
 
+// work counters of the extend kernel: EXT_NQ of them, EXT_QSTRIDE u32 apart (separate cache lines)
+constexpr unsigned EXT_NQ = 8, EXT_QSTRIDE = 64;
+constexpr size_t QUEUE_BYTES = EXT_NQ * EXT_QSTRIDE * 4;
+
 struct ExtendParams {
   DeviceIndex ix;
   ReadBatch reads;

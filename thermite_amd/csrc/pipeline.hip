@@ -127,7 +127,7 @@ int enqueue_run(thm_aligner* a) {
   HIPCHK(a, a->e_ops_off.ensure((n + 2) * 8));
   HIPCHK(a, a->o_alns.ensure(a->cand_cap * sizeof(thm_aln)));
   HIPCHK(a, a->o_ops.ensure(a->cand_ops_cap + 64));
-  HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, 64, s));
+  HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, thm::QUEUE_BYTES, s));
   HIPCHK(a, hipEventRecord(a->ev[2], s));
 
   ExtendParams ep;
