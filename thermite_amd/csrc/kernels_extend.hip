@@ -514,10 +514,31 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
   const unsigned n_total = (unsigned)p.reads.n_reads;
   const unsigned q_share = (n_total + EXT_NQ - 1) / EXT_NQ;
   unsigned my_q = (blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % EXT_NQ, q_tried = 0;
+  // Longest jobs first: reads with many seed hits (repeats; up to a few hundred hits, i.e.
+  // milliseconds, against ~50 us for a typical read) are listed by plan_heavy_kernel and handed
+  // out before everything else, one per wave; left in input order the last ones would start near
+  // the end of the batch and the whole grid would wait for them (a quarter of the kernel's time
+  // on the benchmark workload).
+  bool heavy_phase = true;
+  const unsigned n_heavy = (unsigned)uload(p.heavy_count);
   for (;;) {
+    bool from_heavy = false;
     if (q_next == q_end) {
       bool got = false;
-      while (q_tried < EXT_NQ) {
+      if (heavy_phase) {
+        unsigned g = 0;
+        if (lane == 0) g = atomicAdd(p.queue + EXT_NQ * EXT_QSTRIDE, 1u);
+        g = (unsigned)bcast_first((int)g);
+        if (g < n_heavy) {
+          q_next = (unsigned)uload(&p.heavy[g]);
+          q_end = q_next + 1;
+          got = true;
+          from_heavy = true;
+        } else {
+          heavy_phase = false;
+        }
+      }
+      while (!got && q_tried < EXT_NQ) {
         unsigned g = 0;
         if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, QCHUNK);
         g = (unsigned)bcast_first((int)g);
@@ -559,6 +580,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
     Cand* cands = p.cands + cand0;
     uint32_t* order = p.order + 2 * cand0;  // two scratch lists of the read's hit count each
     const uint64_t n_hits_cap = uload(&p.read_cand_off[idx + 1]) - cand0;
+    if (!from_heavy && n_hits_cap >= HEAVY_HITS) continue;  // went out with the heavy reads
     uint32_t n_acc = 0;
     unsigned acc_bytes = 0;  // op bytes and type of the most recent accepted candidate
     int acc_type = 0;

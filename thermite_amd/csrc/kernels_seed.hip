@@ -567,6 +567,13 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
   }
 }
 
+// reads with many seed hits, for the extend kernel's longest-jobs-first pass
+__global__ __launch_bounds__(256) void plan_heavy_kernel(const uint64_t* read_hits, uint64_t n_reads, unsigned long long* heavy,
+                                                         unsigned long long* count) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  block_append(r < n_reads && read_hits[r] >= HEAVY_HITS, r, heavy, count);
+}
+
 // Mem list of Index::all_smems for thm_smems_batch: one wave per read
 __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
   const int lane = lane_id();
@@ -627,6 +634,13 @@ hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s) {
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(dev::seed_select_kernel, dim3(n_blocks), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_plan_heavy(const uint64_t* read_hits, uint64_t n_reads, unsigned long long* heavy, unsigned long long* count,
+                             hipStream_t s) {
+  if (n_reads == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::plan_heavy_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, read_hits, n_reads, heavy, count);
   return hipGetLastError();
 }
 

@@ -59,6 +59,9 @@ struct SeedParams {
 };
 size_t seed_lds_bytes(uint32_t max_read_len);
 hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s);
+// list the reads with >= HEAVY_HITS hits (after the seed stage): heavy[0 .. *count)
+hipError_t launch_plan_heavy(const uint64_t* read_hits, uint64_t n_reads, unsigned long long* heavy, unsigned long long* count,
+                             hipStream_t s);
 hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded, hipStream_t s);
 
 // expand SMEMs into Mem lists (thm_smems_batch)
@@ -97,7 +100,8 @@ struct Cand {
 
 // work counters of the extend kernel: EXT_NQ of them, EXT_QSTRIDE u32 apart (separate cache lines)
 constexpr unsigned EXT_NQ = 8, EXT_QSTRIDE = 64;
-constexpr size_t QUEUE_BYTES = EXT_NQ * EXT_QSTRIDE * 4;
+constexpr size_t QUEUE_BYTES = (EXT_NQ + 1) * EXT_QSTRIDE * 4;  // + the counter of the heavy-read list
+constexpr unsigned HEAVY_HITS = 8;  // reads with at least this many seed hits are scheduled first
 
 struct ExtendParams {
   DeviceIndex ix;
@@ -107,6 +111,8 @@ struct ExtendParams {
   const uint64_t* read_smem_off;
   const uint32_t* read_smem_cnt;
   const uint64_t* read_cand_off;  // exclusive prefix sum of read_hits: the read's slice of cands[]
+  const unsigned long long* heavy;        // reads with >= HEAVY_HITS hits (plan_heavy_kernel)
+  const unsigned long long* heavy_count;  // [1]
   Cand* cands;
   uint64_t cand_cap;  // entries in cands[] (order[] holds twice as many u32)
   uint32_t* order;  // [total hits] per-read scratch for the final ordering (indices into the read's slice)

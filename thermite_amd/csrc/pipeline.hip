@@ -91,6 +91,9 @@ int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
   sp.queue = a->d_queue.as<unsigned int>();
   sp.fault = a->d_fault.as<int>();
   HIPCHK(a, launch_seed(sp, blocks_for(a, n, seed_lds_bytes(a->max_read_len)), s));
+  // reads with many hits, for the extend kernel's first pass (s_work_reads is free again: the seed kernels are done with it)
+  HIPCHK(a, launch_plan_heavy(a->s_hits.as<uint64_t>(), n, a->s_work_reads.as<unsigned long long>(),
+                              a->s_work_counts.as<unsigned long long>() + 2, s));
   // hit counts -> offsets of each read's slice (also the Mem offsets of thm_smems_batch)
   HIPCHK(a, launch_exclusive_scan_u64(a->s_hits.as<uint64_t>(), a->s_cand_off.as<uint64_t>(), n,
                                       a->scan_tmp.as<uint64_t>(), s));
@@ -140,6 +143,8 @@ int enqueue_run(thm_aligner* a) {
   ep.read_smem_off = a->s_off.as<uint64_t>();
   ep.read_smem_cnt = a->s_cnt.as<uint32_t>();
   ep.read_cand_off = a->s_cand_off.as<uint64_t>();
+  ep.heavy = a->s_work_reads.as<unsigned long long>();
+  ep.heavy_count = a->s_work_counts.as<unsigned long long>() + 2;
   ep.cands = a->e_cands.as<Cand>();
   ep.cand_cap = a->cand_cap;
   ep.order = a->e_order.as<uint32_t>();
