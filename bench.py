@@ -182,8 +182,7 @@ def main():
         "algorithmic_bytes_per_launch": int(ext_bytes), "kernel_ms": round(ext_ms, 4),
         "algorithmic_bytes_per_read_whole_path": round((ext_bytes + seed_bytes - n_r * L) / n_r, 1),
         "stage_ms": {k: round(v / K, 4) for k, v in stage_ms.items()},
-        "note": "integer DP + random index probes: bound by HBM latency / VALU, not HBM bandwidth (SURVEY.md F7); "
-                "traffic includes register-spill scratch of the 5-waves/SIMD build (profiles/pmc_traffic.json)",
+        "note": "integer DP + random index probes: bound by HBM latency / VALU, not HBM bandwidth (SURVEY.md F7)",
     }
 
     # ---------------- CPU baseline (rank 0, N = 1 only) ----------------
