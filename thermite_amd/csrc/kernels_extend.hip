@@ -1076,8 +1076,10 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
 // final layout: alignments of read r at alns[read_aln_off[r]..], op streams back
 // to back in the same order (gx ops, then tx ops of an exonic alignment)
 __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
-  const int lane = lane_id();
-  const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // 16 lanes per read (four reads per wavefront): the work per read is a chain of a few dependent
+  // loads and ~200 bytes of copying, so what counts is how many reads are in flight
+  const int sub = (int)(threadIdx.x & 15u);
+  const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   if (r >= p.n_reads) return;
   const uint32_t n = p.read_n_alns[r];
   if (n == 0) return;
@@ -1090,14 +1092,14 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
   for (uint32_t t = 0; t < n; t++) {
     const Cand cd = cands[la[t]];
     #pragma unroll 1
-    for (uint32_t b = lane; b < cd.ops_len; b += 64) p.ops[o + b] = p.cand_ops[cd.ops_off + b];
+    for (uint32_t b = (uint32_t)sub; b < cd.ops_len; b += 16) p.ops[o + b] = p.cand_ops[cd.ops_off + b];
     const uint64_t go = o;
     o += cd.ops_len;
     #pragma unroll 1
-    for (uint32_t b = lane; b < cd.tx_ops_len; b += 64) p.ops[o + b] = p.cand_ops[cd.tx_ops_off + b];
+    for (uint32_t b = (uint32_t)sub; b < cd.tx_ops_len; b += 16) p.ops[o + b] = p.cand_ops[cd.tx_ops_off + b];
     const uint64_t to = o;
     o += cd.tx_ops_len;
-    if (lane == 0) {
+    if (sub == 0) {
       thm_aln a;
       a.ystart = cd.ystart;
       a.yend = cd.yend;
@@ -1178,7 +1180,7 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
 }
 
 hipError_t launch_compact(const CompactParams& p, hipStream_t s) {
-  const unsigned blocks = (unsigned)((p.n_reads + 3) / 4);
+  const unsigned blocks = (unsigned)((p.n_reads + 15) / 16);
   if (blocks == 0) return hipSuccess;
   hipLaunchKernelGGL(dev::compact_kernel, dim3(blocks), dim3(256), 0, s, p);
   return hipGetLastError();
