@@ -298,7 +298,14 @@ __global__ __launch_bounds__(256) void seed_first_kernel(SeedParams p) {
   }
   const bool covered = active && d >= k && d == L;
   // reads with more positions to look at
-  block_append(active && !covered && L - k + 1 > 1, read, p.work_reads, &p.work_counts[0]);
+  // reads that are not finished here: more positions to probe, or (a single position) left to seed_select_kernel
+  const bool more = active && !covered && L - k + 1 >= 1;
+  block_append(more, read, p.work_reads, &p.work_counts[0]);
+  if (active && !covered && !more) {  // shorter than a seed: no SMEMs
+    p.read_smem_off[read] = 0;
+    p.read_smem_cnt[read] = 0;
+    p.read_hits[read] = 0;
+  }
   // a covered read is done: its one SMEM goes to the pool here (seed_select_kernel skips it)
   const unsigned long long m = __ballot(covered);
   if (m) {
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(256) void seed_grid_kernel(SeedParams p) {
   const uint64_t r0 = p.reads.offsets[read];
   const int L = (int)(p.reads.offsets[read + 1] - r0);
   const int k = (int)p.min_seed_len;
-  const int npos = L - k + 1;  // > 1 for listed reads
+  const int npos = L - k + 1;  // >= 1 for listed reads
   const int pos = (g + 1 == (int)G) ? npos - 1 : g * PROBE_STRIDE;
   // position 0 was probed by seed_first_kernel; the last position is probed once (by the extra slot)
   if (pos <= 0 || pos >= npos || (g + 1 != (int)G && pos == npos - 1)) return;
@@ -434,7 +441,9 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
   // together.  One hot word serves only ~88 M returning atomics per second.
   const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
   const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
-  const unsigned n_static_chunks = (unsigned)(((unsigned long long)p.reads.n_reads * 7 / 8) / QCHUNK / n_waves) * n_waves;
+  // only the reads seed_first_kernel put on the work list are left to do
+  const unsigned n_work = (unsigned)uload(&p.work_counts[0]);
+  const unsigned n_static_chunks = (unsigned)(((unsigned long long)n_work * 7 / 8) / QCHUNK / n_waves) * n_waves;
   unsigned s_chunk = wave_global;
   unsigned long long pool_off = 0;
   unsigned pool_left = 0;
@@ -448,18 +457,16 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
         unsigned g = 0;
         if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
         g = n_static_chunks * QCHUNK + (unsigned)bcast_first((int)g);
-        if (g >= p.reads.n_reads) break;
+        if (g >= n_work) break;
         q_next = g;
-        q_end = min(g + QCHUNK, (unsigned)p.reads.n_reads);
+        q_end = min(g + QCHUNK, n_work);
       }
     }
-    const unsigned idx = q_next++;
+    const unsigned idx = (unsigned)uload(&p.work_reads[q_next++]);
     const uint64_t r0 = uload(&p.reads.offsets[idx]);
     const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
     const int npos = max(L - k + 1, 0);  // positions that were probed
     const uint64_t item0 = (uint64_t)idx * P;
-    // a read whose match from position 0 spans it was finished by seed_first_kernel
-    if (npos > 0 && (int)uload(&p.ms_end[item0]) == L) continue;
 #pragma unroll 1
     for (int t = lane; t < npos; t += 64) a_end[t] = p.ms_end[item0 + t];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
