@@ -463,12 +463,35 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
       }
     }
     const unsigned idx = (unsigned)uload(&p.work_reads[q_next++]);
+    const uint64_t item0 = (uint64_t)idx * P;
+    // Everything that depends only on the read index is requested at once (one memory round
+    // trip): the read's offsets and, for up to 128 positions, its whole row of ends and
+    // intervals; longer rows take the intervals of the SMEM starts in a second trip.
+    const bool row_in_regs = P <= 128u;
+    uint16_t e_r[2] = {0, 0};
+    uint32_t lo_r[2] = {0, 0}, hi_r[2] = {0, 0};
+    if (row_in_regs) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint32_t pos = (uint32_t)(j * 64 + lane);
+        if (pos < P) {
+          e_r[j] = p.ms_end[item0 + pos];
+          lo_r[j] = p.ms_lo[item0 + pos];
+          hi_r[j] = p.ms_hi[item0 + pos];
+        }
+      }
+    }
     const uint64_t r0 = uload(&p.reads.offsets[idx]);
     const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
     const int npos = max(L - k + 1, 0);  // positions that were probed
-    const uint64_t item0 = (uint64_t)idx * P;
+    if (row_in_regs) {
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        if (j * 64 + lane < npos) a_end[j * 64 + lane] = e_r[j];
+    } else {
 #pragma unroll 1
-    for (int t = lane; t < npos; t += 64) a_end[t] = p.ms_end[item0 + t];
+      for (int t = lane; t < npos; t += 64) a_end[t] = p.ms_end[item0 + t];
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
     // SMEM starts: end[i] > end[i-1]; compacted in start order
@@ -488,8 +511,8 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
         const int at = n_sm + __popcll(mask & ((1ull << lane) - 1ull));
         s_pos[at] = (uint16_t)pos;
         s_len[at] = (uint16_t)(e - pos);
-        s_lo[at] = p.ms_lo[item0 + pos];
-        s_hi[at] = p.ms_hi[item0 + pos];
+        s_lo[at] = row_in_regs ? (b0 == 0 ? lo_r[0] : lo_r[1]) : p.ms_lo[item0 + pos];
+        s_hi[at] = row_in_regs ? (b0 == 0 ? hi_r[0] : hi_r[1]) : p.ms_hi[item0 + pos];
       }
       n_sm += __popcll(mask);
     }
