@@ -129,8 +129,9 @@ struct SwgResult {
 // One instruction per step instead of mov-identity + mov_dpp + max.  The two wait
 // states a DPP read needs after a VALU write are in the asm (hipcc pads nothing
 // inside an asm statement).
-__device__ __forceinline__ int wave_excl_max_scan_fast(int v) {
-  int r = NEG;
+// `r` is carried by the caller across columns: lane 0 (which no step writes) keeps the identity it
+// was initialised with, all other lanes are overwritten by the first step.
+__device__ __forceinline__ int wave_excl_max_scan_fast(int v, int& r) {
 #if defined(THM_EXP_NOSCAN)
   return wave_shr1(v, NEG);
 #elif defined(THM_EXP_NONOP)
@@ -220,6 +221,9 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
   for (int c = 0; c < CPL; c++) best_mask[c] = 0;
   bool finished = false;
   unsigned long long* tr = trace + (size_t)CPL * 2;  // column 1
+  int scan_acc = NEG;       // see wave_excl_max_scan_fast
+  int d_shift = MIN_SCORE;  // phase 1: D of the slot above, shifted in from the neighbouring lane; lane 0 (row 0 has no
+                            // diagonal, reference :84) keeps MIN_SCORE because the shift never writes it
   // The counters (cells, columns, last column with cells) are derived after the walk from the
   // last column visited, not maintained per column.
   int last_j = 0;          // last column that computed cells
@@ -251,7 +255,8 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
       yc_next = (int)*yp;  // one past the last column at most: still inside the staged window / LDS
       int d[CPL], Cn[CPL], key[CPL];
       unsigned long long meq[CPL];
-      const int d_in = wave_shr1(Dv[CPL - 1], Dv[CPL - 1]);  // D[b-1] of the previous column for register 0 (lane 0: unused, slot 0 has no diagonal)
+      d_shift = wave_shr1(Dv[CPL - 1], d_shift);  // D[b-1] of the previous column for register 0
+      const int d_in = d_shift;
       int lane_tot = NEG;
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
@@ -260,12 +265,12 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         const int dprev = (c == 0) ? d_in : Dv[c - 1];
         const bool eq = (uint8_t)xc[c] == (uint8_t)yc;
         meq[c] = vote(eq);
-        d[c] = (b == 0) ? MIN_SCORE : dprev + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+        d[c] = dprev + (eq ? MATCH_SCORE : MISMATCH_SCORE);  // slot 0: MIN_SCORE +- 1, never the maximum
         const int dp = max(d[c], Cn[c]);
-        key[c] = valid[c] ? dp - b * ge : NEG;
+        key[c] = dp - b * ge;  // slots without a cell sit above every slot with one: the exclusive scan never feeds them down
         lane_tot = (c == 0) ? key[c] : max(lane_tot, key[c]);
       }
-      int run = wave_excl_max_scan_fast(lane_tot);
+      int run = wave_excl_max_scan_fast(lane_tot, scan_acc);
       unsigned long long m_imp = 0, m_alive = 0, m_c[CPL];
       const int alive_floor = run_max - xlen;  // D + (xlen - i) > run_max  <=>  D - i > run_max - xlen
 #pragma unroll
@@ -361,10 +366,10 @@ __device__ SwgResult swg_extend_wave(const uint8_t* xs, int dx, int xlen, const 
         meq[c] = vote(eq);
         d[c] = Dv[c] + (eq ? MATCH_SCORE : MISMATCH_SCORE);
         const int dp = max(d[c], Cn[c]);
-        key[c] = valid[c] ? dp - b * ge : NEG;
+        key[c] = dp - b * ge;  // slots without a cell sit above every slot with one: the exclusive scan never feeds them down
         lane_tot = (c == 0) ? key[c] : max(lane_tot, key[c]);
       }
-      int run = wave_excl_max_scan_fast(lane_tot);
+      int run = wave_excl_max_scan_fast(lane_tot, scan_acc);
       unsigned long long m_imp = 0, m_alive = 0, m_x = 0, m_c[CPL];
       const int xfloor = run_max - xd;               // X-drop survivors: D >= max_score - x_drop
       const int alive_floor = run_max - xlen + top;  // D + (xlen - i) > run_max  <=>  D - b > run_max - xlen + top
