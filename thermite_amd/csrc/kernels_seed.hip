@@ -18,6 +18,8 @@
 // occurrences of one SMEM are sa[hi-1], ..., sa[lo] (descending rank).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "launch.h"
 #include "swg_device.h"
 
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
   const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
   const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
   // only the reads seed_first_kernel put on the work list are left to do
-  const unsigned n_work = (unsigned)uload(&p.work_counts[0]);
+  const unsigned n_work = (unsigned)uload(p.sel_count);
   const unsigned n_static_chunks = (unsigned)(((unsigned long long)n_work * 7 / 8) / QCHUNK / n_waves) * n_waves;
   unsigned s_chunk = wave_global;
   unsigned long long pool_off = 0;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
         q_end = min(g + QCHUNK, n_work);
       }
     }
-    const unsigned idx = (unsigned)uload(&p.work_reads[q_next++]);
+    const unsigned idx = (unsigned)uload(&p.sel_list[q_next++]);
     const uint64_t item0 = (uint64_t)idx * P;
     // Everything that depends only on the read index is requested at once (one memory round
     // trip): the read's offsets and, for up to 128 positions, its whole row of ends and
@@ -597,6 +599,128 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
   }
 }
 
+// SMEM selection and ordering with one read per THREAD, for the usual case of a handful of SMEMs in
+// a read of at most 255 bases: the work per read is a few hundred instructions behind a chain of
+// dependent loads, so the number of reads in flight is what counts (a wavefront per read leaves the
+// machine waiting).  A read with more than SEL_CAP SMEMs goes on a list for seed_select_kernel.
+constexpr int SEL_CAP = 6;
+
+__global__ __launch_bounds__(256) void seed_select_thread_kernel(SeedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const unsigned T = blockDim.x, tid = threadIdx.x;
+  uint32_t* l_lo = (uint32_t*)smem;             // [SEL_CAP][T]: conflict-free for a wave
+  uint32_t* l_hi = l_lo + (size_t)SEL_CAP * T;  // [SEL_CAP][T]
+  uint32_t* l_pl = l_hi + (size_t)SEL_CAP * T;  // [SEL_CAP][T]: pos | len << 8 | emission index << 16
+  const int lane = lane_id();
+  const uint64_t wi = (uint64_t)blockIdx.x * T + tid;
+  const bool active = wi < p.work_counts[0];
+  const uint32_t P = p.pos_per_read;
+  const int k = (int)p.min_seed_len;
+  int n_sm = 0;
+  bool overflow = false;
+  uint64_t read = 0;
+  if (active) {
+    read = p.work_reads[wi];
+    const uint64_t r0 = p.reads.offsets[read];
+    const int L = (int)(p.reads.offsets[read + 1] - r0);
+    const int npos = max(L - k + 1, 0);
+    const uint64_t item0 = read * P;
+    int prev = 0;
+    // the row of ends, eight positions (16 bytes) per load: rows are 16-byte aligned (the stride is a multiple of 8)
+    const uint4* row = (const uint4*)(p.ms_end + item0);
+    for (int c0 = 0; c0 < npos; c0 += 8) {
+      const uint4 v = row[c0 >> 3];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int pos = c0 + j;
+        const int e = (int)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        if (pos < npos && e > 0 && e > prev) {  // an SMEM starts here
+          if (n_sm < SEL_CAP) {
+            l_lo[(size_t)n_sm * T + tid] = p.ms_lo[item0 + (uint64_t)pos];
+            l_hi[(size_t)n_sm * T + tid] = p.ms_hi[item0 + (uint64_t)pos];
+            l_pl[(size_t)n_sm * T + tid] = (uint32_t)pos | ((uint32_t)(e - pos) << 8);
+          } else {
+            overflow = true;
+          }
+          n_sm++;
+        }
+        prev = e;
+      }
+    }
+    if (overflow) n_sm = 0;
+  }
+  block_append(overflow, read, p.sel_list_out, p.sel_count_out);
+
+  // emission order of FMDIndex::all_smems over the read's SMEMs (in start order), as in seed_select_kernel
+  if (n_sm > 1) {
+    int t = 0, em = 0, i0 = 0;
+    while (t < n_sm) {
+      const int st = (int)(l_pl[(size_t)t * T + tid] & 0xffu);
+      if (st > i0) i0 = st;
+      int u = t;
+      while (u < n_sm && (int)(l_pl[(size_t)u * T + tid] & 0xffu) <= i0) u++;
+      for (int v = u - 1; v >= t; v--) l_pl[(size_t)v * T + tid] |= (uint32_t)(em + (u - 1 - v)) << 16;
+      em += u - t;
+      const uint32_t z = l_pl[(size_t)(u - 1) * T + tid];
+      i0 = (int)(z & 0xffu) + (int)((z >> 8) & 0xffu);
+      t = u;
+    }
+  }
+  // pool entries of the wave: exclusive prefix sum of n_sm over the lanes, one atomic for the total
+  int incl = n_sm;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  const int total = __shfl(incl, 63);
+  unsigned long long base = 0;
+  if (total > 0) {
+    if (lane == 0) base = atomicAdd(p.cursor, (unsigned long long)total);
+    base = ((unsigned long long)(unsigned)bcast_first((int)(base >> 32)) << 32) | (unsigned)bcast_first((int)(base & 0xffffffffu));
+  }
+  const bool fits = base + (unsigned long long)total <= p.smem_cap;
+  const unsigned long long mine = base + (unsigned long long)(incl - n_sm);
+  unsigned long long hits = 0;
+  for (int t = 0; t < n_sm; t++) {
+    const uint32_t a = l_pl[(size_t)t * T + tid];
+    const int len = (int)((a >> 8) & 0xffu), em = (int)(a >> 16);
+    int rank = 0;
+    for (int u = 0; u < n_sm; u++) {
+      const uint32_t b = l_pl[(size_t)u * T + tid];
+      const int lu = (int)((b >> 8) & 0xffu), eu = (int)(b >> 16);
+      rank += (lu > len || (lu == len && eu > em)) ? 1 : 0;
+    }
+    const uint32_t slo = l_lo[(size_t)t * T + tid], shi = l_hi[(size_t)t * T + tid];
+    if (fits) {
+      Smem sm;
+      sm.lo = slo;
+      sm.hi = shi;
+      sm.qpos = (uint16_t)(a & 0xffu);
+      sm.len = (uint16_t)len;
+      p.smems[mine + rank] = sm;
+    }
+    hits += (unsigned long long)(shi - slo);
+  }
+  if (active && !overflow) {
+    p.read_smem_off[read] = mine;
+    p.read_smem_cnt[read] = (uint32_t)n_sm;
+    p.read_hits[read] = hits;
+  }
+  int fault = (total > 0 && !fits) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) {
+    hits += __shfl_xor(hits, o);
+    fault |= __shfl_xor(fault, o);
+  }
+  if (lane == 0) {
+    if (fault) atomicExch(p.fault, 1);
+    if (total > 0) {
+      atomicAdd(&p.counters[THM_CNT_SMEMS], (unsigned long long)total);
+      atomicAdd(&p.counters[THM_CNT_HITS], hits);
+    }
+  }
+}
+
 // reads with many seed hits, for the extend kernel's longest-jobs-first pass
 __global__ __launch_bounds__(256) void plan_heavy_kernel(const uint64_t* read_hits, uint64_t n_reads, unsigned long long* heavy,
                                                          unsigned long long* count) {
@@ -658,12 +782,29 @@ hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s) {
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
   }
+  // SMEM selection: one read per thread when positions and lengths fit a byte, its overflow list
+  // (or, for longer reads, the whole work list) through the wavefront-per-read kernel
+  SeedParams q = p;
+  if (p.max_read_len <= 255 && n) {
+    q.sel_list_out = p.work_cells;  // free again: seed_fill_kernel is done with it
+    q.sel_count_out = p.work_counts + 3;
+    hipLaunchKernelGGL(dev::seed_select_thread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                       (size_t)256 * 4 * 3 * dev::SEL_CAP, s, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    q.sel_list = p.work_cells;
+    q.sel_count = p.work_counts + 3;
+    n_blocks = std::min(n_blocks, 256);  // the overflow list is short: every wave costs an atomic just to find it empty
+  } else {
+    q.sel_list = p.work_reads;
+    q.sel_count = p.work_counts;
+  }
   const size_t lds = seed_lds_bytes(p.max_read_len);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)dev::seed_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(dev::seed_select_kernel, dim3(n_blocks), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(dev::seed_select_kernel, dim3(n_blocks), dim3(256), lds, s, q);
   return hipGetLastError();
 }
 

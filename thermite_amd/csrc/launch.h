@@ -40,13 +40,17 @@ struct SeedParams {
   ReadBatch reads;
   uint32_t min_seed_len;
   uint32_t max_read_len;       // LDS sizing
-  uint32_t pos_per_read;       // max_read_len - min_seed_len + 1 (>= 1): probe slots per read
+  uint32_t pos_per_read;       // probe slots per read: max_read_len - min_seed_len + 1 (>= 1) rounded up to 8; the row stride
   uint16_t* ms_end;            // [n_reads * pos_per_read] end of the longest match from this position (0: < k)
   uint32_t* ms_lo;             // its suffix-array interval
   uint32_t* ms_hi;
   unsigned long long* work_reads;   // [n_reads] reads that need more than the probe at position 0
   unsigned long long* work_cells;   // [n_reads * cells per read] (read << 16 | cell) of grid cells to probe
-  unsigned long long* work_counts;  // [2] list lengths, zeroed before launch
+  unsigned long long* work_counts;  // [4] list lengths ([2]: heavy reads, [3]: select overflow), zeroed before launch
+  const unsigned long long* sel_list;   // reads seed_select_kernel goes through, and how many (set by launch_seed)
+  const unsigned long long* sel_count;
+  unsigned long long* sel_list_out;     // seed_select_thread_kernel: reads with more SMEMs than its list holds
+  unsigned long long* sel_count_out;
   Smem* smems;                 // pool
   uint64_t smem_cap;           // pool capacity (entries)
   unsigned long long* cursor;  // bump allocator head (entries), zeroed before launch

@@ -55,7 +55,8 @@ int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
   // to_ascii_uppercase (src/aligner.rs:125) + sanitising, once per run for both kernels
   HIPCHK(a, a->r_san.ensure(a->n_bases + 256));
   HIPCHK(a, launch_sanitize(a->r_bases.as<uint8_t>(), a->r_san.as<uint8_t>(), a->n_bases, a->n_bases + 128, s));
-  const uint32_t P = (a->max_read_len >= min_seed_len) ? a->max_read_len - min_seed_len + 1 : 1;
+  // probe slots per read, rounded up to 8 so that a read's row of ends starts on a 16-byte boundary
+  const uint32_t P = (((a->max_read_len >= min_seed_len) ? a->max_read_len - min_seed_len + 1 : 1) + 7u) & ~7u;
   const uint64_t items = n * (uint64_t)P;
   HIPCHK(a, a->s_ms_end.ensure(items * 2 + 64));
   HIPCHK(a, a->s_ms_lo.ensure(items * 4 + 64));
