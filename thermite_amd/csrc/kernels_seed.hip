@@ -226,11 +226,24 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
 // upper-case + sanitise the batch once (reference src/aligner.rs:125); both the
 // probe kernel and the extend kernel read this copy
 __global__ void sanitize_kernel(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    out[i] = sanitize_base(in[i]);
-  else if (i < n_padded)
-    out[i] = 0;
+  // 16 bytes per thread (both buffers come from hipMalloc and are padded past n_padded)
+  const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i >= n_padded) return;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (i < n) v = *(const uint4*)(in + i);  // may read up to 15 bytes past n: inside the allocation's slack
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint64_t at = i + (uint64_t)(4 * j + b);
+      const uint8_t c = (at < n) ? sanitize_base((uint8_t)(w[j] >> (8 * b))) : (uint8_t)0;
+      r |= (uint32_t)c << (8 * b);
+    }
+    w[j] = r;
+  }
+  *(uint4*)(out + i) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // Matching statistics by probing fewer and fewer positions.  E[i] = i + MS[i], the end of
@@ -759,7 +772,7 @@ size_t seed_lds_bytes(uint32_t max_read_len) {
 
 hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded, hipStream_t s) {
   if (n_padded == 0) return hipSuccess;
-  hipLaunchKernelGGL(dev::sanitize_kernel, dim3((unsigned)((n_padded + 255) / 256)), dim3(256), 0, s, in, out, n, n_padded);
+  hipLaunchKernelGGL(dev::sanitize_kernel, dim3((unsigned)((n_padded / 16 + 255) / 256 + 1)), dim3(256), 0, s, in, out, n, n_padded);
   return hipGetLastError();
 }
 
