@@ -110,6 +110,24 @@ def test_chrm_long_reads_wide_band(chrm):
     check_align(chrm, bases, off, opts)
 
 
+def test_reads_longer_than_255_bases(chrm):
+    """300 bp reads (ragged down to 0): the position-per-byte paths of the seed stage do not apply --
+    SMEM selection runs one read per wavefront over the whole work list, rows of ends exceed 128 positions --
+    and reads with many SMEMs (a low k) overflow the per-thread lists of the short-read path."""
+    rng = np.random.default_rng(23)
+    bases, off, _ = synth.simulate_reads(chrm.t, 1500, 300, sub_rate=0.03, indel_rate=0.005, stream=9)
+    reads = [bases[off[i]: off[i] + (300 if i % 3 else int(rng.integers(0, 301)))] for i in range(1500)]
+    b2, o2 = refdata.pack_reads(reads)
+    check_smems(chrm, b2, o2, 20)
+    check_smems(chrm, b2, o2, 9)
+    opts = dict(min_seed_len=20, min_aln_score_percent=0.9, min_aln_score=30, multimap_score_range=1, intron_mode=True)
+    check_align(chrm, b2, o2, opts)
+    # the short-read path with a low k: many SMEMs per read (more than six overflow to the wavefront kernel)
+    bases, off, _ = synth.simulate_reads(chrm.t, 3000, 120, sub_rate=0.08, indel_rate=0.01, stream=10)
+    check_smems(chrm, bases, off, 8)
+    check_align(chrm, bases, off, dict(capi.CI_OPTS, min_seed_len=8, min_aln_score_percent=0.5))
+
+
 def test_ragged_lengths(chrm):
     rng = np.random.default_rng(11)
     bases, off, _ = synth.simulate_reads(chrm.t, 4000, 120, sub_rate=0.01, stream=7)
