@@ -1,18 +1,18 @@
 // kernels_seed.hip -- seed lookup: all supermaximal exact matches (SMEMs) of
 // length >= min_seed_len of each read against the both-strand text, i.e. the
-// result of Index::all_smems (reference src/index.rs:228-255), one read per
-// wavefront.
+// result of Index::all_smems (reference src/index.rs:228-255).
 //
 // The reference walks an FMD index (bio 0.37.1, ~2L dependent Occ lookups per
-// read).  Here every read position is searched independently by one thread
-// (probe kernel: one thread per read position, so a wave never waits on a second
-// pass over one read) and a second kernel picks and orders the SMEMs per read:
+// read).  Here a read position is searched by one thread (ms_search):
 //     kt-mer prefix table  ->  suffix-array interval  ->  refine by binary search
 //     on (sa, text)  ->  once one suffix is left, 8-byte compares along the text.
-// That yields the matching statistics MS[i]; position i starts an SMEM iff
+// That yields the matching statistic MS[i]; position i starts an SMEM iff
 // i + MS[i] > (i-1) + MS[i-1], and only matches of
 // length >= k are needed, so positions whose kt-mer is absent stop after one
-// table probe.  The SMEMs are then put in the order the reference's
+// table probe.  Because the match end i + MS[i] never decreases with i, most
+// positions need no probe at all: the kernels below probe position 0, then a
+// stride-8 grid, then only the grid cells around a jump of the end (work lists
+// keep those launches dense).  The SMEMs are then put in the order the reference's
 // `mems.sort_by_key(len); mems.reverse()` produces:
 // length descending, ties by reverse emission order of FMDIndex::all_smems;
 // occurrences of one SMEM are sa[hi-1], ..., sa[lo] (descending rank).

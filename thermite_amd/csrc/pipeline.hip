@@ -3,7 +3,7 @@
 //   thm_align_batch (= the three in sequence) and thm_smems_batch.
 //
 // One batch = count -> scan -> fill on the device:
-//   seed kernel     SMEMs per read (pool + per-read run), hit counts
+//   seed kernels    SMEMs per read (pool + per-read run), hit counts, list of reads with many hits
 //   scan            hit counts -> per-read slice of the candidate array
 //   extend kernel   align_read per read; accepted alignments into the slice,
 //                   op streams into a bump-allocated pool; final order list
