@@ -44,3 +44,13 @@ def test_cpp_mirror_header_compiles(tmp_path):
     src = tmp_path / "t.cpp"
     src.write_text('#include "thermite.hpp"\nint main() { thermite::AlignOpts o; return (int)o.min_seed_len - 20; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(root, "include"), "-fsyntax-only", str(src)])
+
+
+def test_c_headers_are_plain_c(tmp_path):
+    """the boundary is a C ABI: both headers must compile as C99, not only as C++"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "thermite_io.h"\nint main(void) { thm_run_stats s; thm_aln a; (void)s; (void)a; return THM_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+                           "-fsyntax-only", str(src)])
