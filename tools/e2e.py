@@ -37,5 +37,19 @@ for fmt, name in ((capi.FMT_SAM, "sam"), (capi.FMT_PAF, "paf")):
         print("%s run %d: %.2f Mreads/s wall %.2fs | parse %.2fs gpu %.2fs format %.2fs write %.2fs | %d batches, %.0f MB out" % (
             name, rep, st["n_reads"] / st["wall_s"] / 1e6, st["wall_s"], st["parse_s"], st["gpu_s"], st["format_s"], st["write_s"],
             st["n_batches"], st["n_output_bytes"] / 1e6), flush=True)
+# gzip input: one zlib thread inflates
+import gzip, shutil
+gz = path + ".gz"
+t0 = time.time()
+with open(path, "rb") as fi, gzip.open(gz, "wb", compresslevel=1) as fo:
+    shutil.copyfileobj(fi, fo, 1 << 24)
+print("gzip: %.1f MB in %.1fs" % (os.path.getsize(gz) / 1e6, time.time() - t0), flush=True)
+st = capi.align_files(a, [gz], "/tmp/thm_e2e_out.paf", capi.FMT_PAF, batch_reads=250000, n_threads=threads)
+print("paf from .gz: %.2f Mreads/s wall %.2fs | parse %.2fs gpu %.2fs format %.2fs write %.2fs" % (
+    st["n_reads"] / st["wall_s"] / 1e6, st["wall_s"], st["parse_s"], st["gpu_s"], st["format_s"], st["write_s"]), flush=True)
+st = capi.align_files(a, [path], "/tmp/thm_e2e_out.bam", capi.FMT_BAM, batch_reads=250000, n_threads=threads)
+print("bam: %.2f Mreads/s wall %.2fs | parse %.2fs gpu %.2fs format %.2fs write %.2fs | %.0f MB out" % (
+    st["n_reads"] / st["wall_s"] / 1e6, st["wall_s"], st["parse_s"], st["gpu_s"], st["format_s"], st["write_s"], st["n_output_bytes"] / 1e6), flush=True)
 a.close()
 os.remove(path)
+os.remove(gz)
