@@ -1151,15 +1151,16 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
-  // register budget: MINW waves per SIMD.  Default 5 for the one- and two-cell-per-lane kernels
-  // (96 VGPRs with a handful of spilled ones; LDS admits 5 workgroups per CU for 91 bp reads),
-  // 4 for wider bands; tuning knob THM_EXT_MINW = 2..6 | 8.
+  // register budget: MINW waves per SIMD.  Defaults, measured: 8 for the one-cell-per-lane kernel
+  // (64 VGPRs plus spilled ones; its LDS footprint admits 8 workgroups per CU for 91 bp reads), 5 for
+  // the two-cell-per-lane kernel (96 VGPRs, no scratch; LDS admits 5 workgroups), 4 for wider bands;
+  // tuning knob THM_EXT_MINW = 2..6 | 8.
   static const int minw_env = [] {
     const char* e = getenv("THM_EXT_MINW");
     const int v = e ? atoi(e) : 0;
     return (v >= 2 && v <= 8) ? v : 0;
   }();
-  const int minw = minw_env ? minw_env : (cpl <= 2 ? 5 : 4);
+  const int minw = minw_env ? minw_env : (cpl == 1 ? 8 : (cpl == 2 ? 5 : 4));
 #define THM_EXT_CASE(C)                                  \
   case C:                                                \
     if (minw == 4) return go(dev::extend_kernel<C, 4>);  \
