@@ -100,7 +100,7 @@ struct thm_aligner {
   DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp, s_ms_end, s_ms_lo, s_ms_hi, s_work_reads, s_work_cells, s_work_counts;
   uint64_t smem_cap = 0;
   // extension
-  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off;
+  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace;
   uint64_t cand_cap = 0, cand_ops_cap = 0;
   // compacted outputs
   DBuf o_alns, o_ops, o_mems;

@@ -71,7 +71,8 @@ struct Wctx {
   uint8_t* rd;   // sanitised read, zero padded
   uint8_t* win;   // window the extension reads (genome or transcript; 16-byte aligned copy)
   uint8_t* wing;  // the hit's genome window, kept while its transcripts are tried
-  unsigned long long* trace;
+  unsigned long long* trace;    // LDS: trace of a one-cell-per-lane extension (16 bytes per column)
+  unsigned long long* trace_g;  // global memory: trace of a wider extension (rare for 91 bp reads; keeps the LDS footprint small)
   uint8_t* pa;  // three path buffers (op kinds 0..3), rotated by pointer swap
   uint8_t* pb;
   uint8_t* pc;
@@ -208,10 +209,16 @@ __device__ __forceinline__ int swg_and_trace(Wctx& c, const uint8_t* xs, int dx,
     PROF_MARK(c, PS_DP);
     n = swg_traceback_wave<1>(c.trace, r.xend, r.yend, bw, ops, stride, max_ops);
   } else {
-    r = swg_extend_wave<CPL>(xs, dx, xlen, ys, dy, ylen, bw, xd, c.trace);
-    wfence();
+    // more than 64 band slots: the trace (CPL * 16 bytes per column) goes to the wave's scratch in global
+    // memory; the stores of lane 0 must be visible to the loads of all lanes, hence the agent-scope fence
+    unsigned long long* tr = (CPL > 1) ? c.trace_g : c.trace;
+    r = swg_extend_wave<CPL>(xs, dx, xlen, ys, dy, ylen, bw, xd, tr);
+    if (CPL > 1)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    else
+      wfence();
     PROF_MARK(c, PS_DP);
-    n = swg_traceback_wave<CPL>(c.trace, r.xend, r.yend, bw, ops, stride, max_ops);
+    n = swg_traceback_wave<CPL>(tr, r.xend, r.yend, bw, ops, stride, max_ops);
   }
   wfence();
   PROF_MARK(c, PS_TRACEBACK);
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
   const uint32_t lcap = (p.max_read_len + 31u) & ~15u;
   const uint32_t wcap = (2u * (p.max_read_len + p.max_bw) + p.max_read_len + 48u) & ~15u;
   const uint32_t ycols = p.max_read_len + p.max_bw + 2u;
-  const uint32_t trb = (ycols + 1u) * CPL * 16u;
+  const uint32_t trb = (ycols + 1u) * 16u;  // LDS trace: one cell per lane; wider extensions use trace_g
   const uint32_t opcap = (2u * p.max_read_len + 2u * p.max_bw + 31u) & ~15u;
   const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * MAX_YCLIPS;
   uint8_t* base = smem + (size_t)wave * per_wave;
@@ -480,6 +487,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
   c.win = c.rd + lcap;
   c.wing = c.win + wcap;
   c.trace = (unsigned long long*)(c.wing + wcap);
+  c.trace_g = p.trace_scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) * ((size_t)(ycols + 1u) * CPL * 2u);
   c.pa = (uint8_t*)c.trace + trb;
   c.pb = c.pa + opcap;
   c.pc = c.pb + opcap;
@@ -1135,10 +1143,16 @@ size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
   const uint32_t lcap = (max_read_len + 31u) & ~15u;
   const uint32_t wcap = (2u * (max_read_len + max_bw) + max_read_len + 48u) & ~15u;
   const uint32_t ycols = max_read_len + max_bw + 2u;
-  const uint32_t trb = (ycols + 1u) * cpl * 16u;
+  const uint32_t trb = (ycols + 1u) * 16u;
   const uint32_t opcap = (2u * max_read_len + 2u * max_bw + 31u) & ~15u;
   const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * dev::MAX_YCLIPS;
+  (void)cpl;
   return 4 * (size_t)per_wave;
+}
+
+// global trace scratch of one wave (extensions over more than 64 band slots), in bytes
+size_t extend_trace_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
+  return cpl > 1 ? (size_t)(max_read_len + max_bw + 3u) * (size_t)cpl * 16u : 0;
 }
 
 hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream_t s) {
@@ -1151,16 +1165,18 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
-  // register budget: MINW waves per SIMD.  Defaults, measured: 8 for the one-cell-per-lane kernel
-  // (64 VGPRs plus spilled ones; its LDS footprint admits 8 workgroups per CU for 91 bp reads), 5 for
-  // the two-cell-per-lane kernel (96 VGPRs, no scratch; LDS admits 5 workgroups), 4 for wider bands;
-  // tuning knob THM_EXT_MINW = 2..6 | 8.
+  // register budget: MINW waves per SIMD.  Defaults, measured: 8 for the one-cell-per-lane kernel (64
+  // VGPRs plus spilled ones), 6 for the two-cell-per-lane kernel (80 VGPRs plus spilled ones; with
+  // the wide-band trace in global memory its LDS footprint admits 8 workgroups per CU for 91 bp
+  // reads), 4 for wider bands.  The spilled registers cost scratch traffic (2-3 GB per 500 k-read
+  // launch, against a kernel that uses 2 % of the HBM bandwidth) and buy 8 % more throughput than 5
+  // waves without spills; tuning knob THM_EXT_MINW = 2..6 | 8.
   static const int minw_env = [] {
     const char* e = getenv("THM_EXT_MINW");
     const int v = e ? atoi(e) : 0;
     return (v >= 2 && v <= 8) ? v : 0;
   }();
-  const int minw = minw_env ? minw_env : (cpl == 1 ? 8 : (cpl == 2 ? 5 : 4));
+  const int minw = minw_env ? minw_env : (cpl == 1 ? 8 : (cpl == 2 ? 6 : 4));
 #define THM_EXT_CASE(C)                                  \
   case C:                                                \
     if (minw == 4) return go(dev::extend_kernel<C, 4>);  \

@@ -130,9 +130,11 @@ struct ExtendParams {
   int* fault;  // bit 0: op pool overflow, bit 1: internal inconsistency, bit 2: out-of-contract (lift failure)
   uint32_t max_read_len;
   uint32_t max_bw;
+  unsigned long long* trace_scratch;  // [waves in the grid * extend_trace_scratch_bytes / 8] (unused when cpl == 1)
   unsigned long long* prof;  // 16 slots of shader clocks per section (THM_PROF builds), else unused
 };
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
+size_t extend_trace_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
 hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream_t s);
 
 struct CompactParams {

@@ -160,7 +160,10 @@ int enqueue_run(thm_aligner* a) {
   ep.max_read_len = a->max_read_len;
   ep.max_bw = bw_max;
   ep.prof = a->d_counters.as<unsigned long long>() + 2 * THM_N_COUNTERS;
-  HIPCHK(a, launch_extend(ep, cpl, blocks_for(a, n, lds), s));
+  const int ext_blocks = blocks_for(a, n, lds);
+  HIPCHK(a, a->e_trace.ensure((size_t)ext_blocks * 4 * extend_trace_scratch_bytes(a->max_read_len, bw_max, cpl) + 64));
+  ep.trace_scratch = a->e_trace.as<unsigned long long>();
+  HIPCHK(a, launch_extend(ep, cpl, ext_blocks, s));
   HIPCHK(a, hipEventRecord(a->ev[3], s));
 
   HIPCHK(a, launch_widen_u32_to_u64(a->e_nalns.as<uint32_t>(), a->e_nalns64.as<uint64_t>(), n, s));
