@@ -208,6 +208,13 @@ __device__ __forceinline__ int swg_and_trace(Wctx& c, const uint8_t* xs, int dx,
     wfence();
     PROF_MARK(c, PS_DP);
     n = swg_traceback_wave<1>(c.trace, r.xend, r.yend, bw, ops, stride, max_ops);
+  } else if (CPL > 2 && min(2 * bw + 1, xlen + 1) <= 128) {
+    // fits two cells per lane: a third fewer instructions per column than the kernel's own width
+    unsigned long long* tr = c.trace_g;
+    r = swg_extend_wave<2>(xs, dx, xlen, ys, dy, ylen, bw, xd, tr);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    PROF_MARK(c, PS_DP);
+    n = swg_traceback_wave<2>(tr, r.xend, r.yend, bw, ops, stride, max_ops);
   } else {
     // more than 64 band slots: the trace (CPL * 16 bytes per column) goes to the wave's scratch in global
     // memory; the stores of lane 0 must be visible to the loads of all lanes, hence the agent-scope fence
