@@ -513,7 +513,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
 #endif
 
   auto& ix = p.ix;
-  unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_type[3] = {0, 0, 0}, k_reads = 0, k_opb = 0;
+  unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_reads = 0, k_opb = 0;
+  unsigned k_type[3] = {0, 0, 0};  // wave-uniform (counted with ballots)
   unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
 
   // Reads are handed out by atomic counters, QCHUNK at a time.  Small chunks balance the waves
@@ -937,11 +938,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
       nres = 1;
       if (lane == 0) order[0] = 0;
       opb = acc_bytes;
-      if (lane == 0) {
-        k_type[0] += (acc_type == THM_ALN_EXONIC);
-        k_type[1] += (acc_type == THM_ALN_INTRONIC);
-        k_type[2] += (acc_type == THM_ALN_INTERGENIC);
-      }
+      k_type[0] += (acc_type == THM_ALN_EXONIC);
+      k_type[1] += (acc_type == THM_ALN_INTRONIC);
+      k_type[2] += (acc_type == THM_ALN_INTERGENIC);
     } else if (n_acc > 1) {
       __threadfence_block();
     // ============ retain / filter_overlapping / sort / primary (:177-187) ============
@@ -1032,12 +1031,17 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
     }
       // per-read totals
       #pragma unroll 1
-      for (uint32_t t = lane; t < nres; t += 64) {
-        const Cand a = cands[la[t]];
-        opb += a.ops_len + a.tx_ops_len;
-        k_type[0] += (a.aln_type == THM_ALN_EXONIC);
-        k_type[1] += (a.aln_type == THM_ALN_INTRONIC);
-        k_type[2] += (a.aln_type == THM_ALN_INTERGENIC);
+      for (uint32_t t0 = 0; t0 < nres; t0 += 64) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        int ty = -1;
+        if (t < nres) {
+          const Cand a = cands[la[t]];
+          opb += a.ops_len + a.tx_ops_len;
+          ty = a.aln_type;
+        }
+        k_type[0] += (unsigned)__popcll(__ballot(ty == THM_ALN_EXONIC));
+        k_type[1] += (unsigned)__popcll(__ballot(ty == THM_ALN_INTRONIC));
+        k_type[2] += (unsigned)__popcll(__ballot(ty == THM_ALN_INTERGENIC));
       }
       for (int o = 32; o > 0; o >>= 1) opb += __shfl_xor(opb, o);
     }
@@ -1060,8 +1064,6 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
     c.cells = c.cols = c.calls = c.winbytes = 0;
     wfence();
   }
-  for (int t = 0; t < 3; t++)
-    for (int o = 32; o > 0; o >>= 1) k_type[t] += __shfl_xor(k_type[t], o);
 #ifdef THM_PROF
   if (lane == 0 && p.prof)
     {
@@ -1076,9 +1078,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
       atomicAdd(&p.counters[THM_CNT_ALIGNED], k_aligned);
       atomicAdd(&p.counters[THM_CNT_UNMAPPED], k_unmapped);
       atomicAdd(&p.counters[THM_CNT_ALNS], k_alns);
-      atomicAdd(&p.counters[THM_CNT_EXONIC], k_type[0]);
-      atomicAdd(&p.counters[THM_CNT_INTRONIC], k_type[1]);
-      atomicAdd(&p.counters[THM_CNT_INTERGENIC], k_type[2]);
+      atomicAdd(&p.counters[THM_CNT_EXONIC], (unsigned long long)k_type[0]);
+      atomicAdd(&p.counters[THM_CNT_INTRONIC], (unsigned long long)k_type[1]);
+      atomicAdd(&p.counters[THM_CNT_INTERGENIC], (unsigned long long)k_type[2]);
       atomicAdd(&p.counters[THM_CNT_SWG_CALLS], k_calls);
       atomicAdd(&p.counters[THM_CNT_DP_CELLS], k_cells);
       atomicAdd(&p.counters[THM_CNT_DP_COLS], k_cols);
