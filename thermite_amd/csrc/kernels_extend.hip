@@ -1177,9 +1177,9 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
   // register budget: MINW waves per SIMD.  Defaults, measured: 8 for the one-cell-per-lane kernel (64
   // VGPRs plus spilled ones), 6 for the two-cell-per-lane kernel (80 VGPRs plus spilled ones; with
   // the wide-band trace in global memory its LDS footprint admits 8 workgroups per CU for 91 bp
-  // reads), 4 for wider bands.  The spilled registers cost scratch traffic (2-3 GB per 500 k-read
+  // reads), 4 for wider bands.  The spilled registers cost scratch traffic (about 0.6 GB per 500 k-read
   // launch, against a kernel that uses 2 % of the HBM bandwidth) and buy 8 % more throughput than 5
-  // waves without spills; tuning knob THM_EXT_MINW = 2..6 | 8.
+  // waves; tuning knob THM_EXT_MINW = 2..6 | 8.
   static const int minw_env = [] {
     const char* e = getenv("THM_EXT_MINW");
     const int v = e ? atoi(e) : 0;
