@@ -180,3 +180,81 @@ def test_option_sweep_with_dirty_reads(syn, opts):
     b[lower] = np.where((b[lower] >= 65) & (b[lower] <= 90), b[lower] + 32, b[lower])
     check_smems(syn, b, off, opts["min_seed_len"])
     check_align(syn, b, off, opts)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5's read shape (150 bp, band +-64 and wider) on spliced, two-strand,
+# repeat-bearing input: the 3- and 4-cells-per-lane kernels, the global-memory trace, the
+# two-cell dispatch inside a wider kernel, lift_markers over real introns and the
+# multi-candidate retain / overlap path (reference src/swg.rs:116-154, src/txome.rs:110-160,
+# src/aligner.rs:137-175).
+CONFIG5_OPTS = dict(min_seed_len=20, min_aln_score_percent=0.574, min_aln_score=30, multimap_score_range=1, intron_mode=True)
+
+
+def test_config5_shape_spliced_two_strand_repeats(syn):
+    """150 bp, percent 0.574 -> ms 86 -> bw 64 (3 cells per lane) on multi-exon transcripts of both strands"""
+    bases, off, _ = synth.simulate_reads(syn.t, 12000, 150, sub_rate=0.02, indel_rate=0.004, intronic_frac=0.25, stream=31)
+    check_smems(syn, bases, off, 20)
+    check_align(syn, bases, off, CONFIG5_OPTS)
+    check_align(syn, bases, off, dict(CONFIG5_OPTS, multimap_score_range=4, min_seed_len=14))
+    noisy, off2, _ = synth.simulate_reads(syn.t, 6000, 150, sub_rate=0.06, indel_rate=0.012, intronic_frac=0.25, stream=32)
+    check_align(syn, noisy, off2, CONFIG5_OPTS)
+
+
+@pytest.mark.parametrize("L,pct,bw", [(120, 0.0, 90), (150, 0.0, 120), (157, 0.0, 127), (150, 0.3, 105), (130, 0.5, 65)])
+def test_read_level_bands_65_to_127(syn, L, pct, bw):
+    """read-level parity for bands +-65..+-127 (the reference's chr21 flags -s0 give bw = L - 30)"""
+    opts = dict(capi.CI_OPTS, min_aln_score_percent=pct)
+    assert L - max(int(np.float32(pct) * np.float32(L)), 30) == bw
+    bases, off, _ = synth.simulate_reads(syn.t, 5000, L, sub_rate=0.03, indel_rate=0.006, intronic_frac=0.25, stream=40 + L)
+    check_align(syn, bases, off, opts)
+
+
+def test_fuzz_bounded(syn):
+    """bounded run of the randomised differential test (tools/fuzz_gpu.py): random options, ragged and
+    dirty reads, seed-level and read-level parity with the oracle"""
+    rng = np.random.default_rng(2)
+    for r in range(8):
+        L = int(rng.choice([30, 50, 75, 91, 120, 150, 200, 260]))
+        k = int(rng.integers(8, 26))
+        pct = float(rng.choice([0.0, 0.3, 0.5, 0.66, 0.8, 0.9]))
+        opts = dict(min_seed_len=k, min_aln_score_percent=pct, min_aln_score=int(rng.choice([0, 20, 30])),
+                    multimap_score_range=int(rng.integers(0, 4)), intron_mode=bool(rng.integers(0, 2)))
+        n = int(rng.integers(500, 3000))
+        bases, off, _ = synth.simulate_reads(syn.t, n, L, sub_rate=float(rng.choice([0.0, 0.01, 0.03, 0.08])),
+                                             indel_rate=float(rng.choice([0.0, 0.002, 0.01])), intronic_frac=0.2, stream=1000 + r)
+        b = bases.copy()
+        for ch, p in ((ord("N"), 0.002), (ord("x"), 0.0003)):
+            b[rng.random(len(b)) < p] = ch
+        lower = rng.random(len(b)) < 0.2
+        b[lower] = np.where((b[lower] >= 65) & (b[lower] <= 90), b[lower] + 32, b[lower])
+        reads = [b[int(off[i]): int(off[i]) + (L if rng.random() < 0.7 else int(rng.integers(0, L + 1)))] for i in range(n)]
+        b2, o2 = refdata.pack_reads(reads)
+        check_smems(syn, b2, o2, k)
+        check_align(syn, b2, o2, opts)
+
+
+# ---------------------------------------------------------------------------------------------
+# pool overflow -> grow -> replay (thm_batch_sync): the faulted attempt must neither write out of bounds
+# nor change the result
+def test_pool_overflow_replay(syn, chrm):
+    bases, off, _ = synth.simulate_reads(syn.t, 6000, 91, sub_rate=0.02, indel_rate=0.004, intronic_frac=0.25, stream=77)
+    ref = syn.oix.align_batch(bases, off, capi.CI_OPTS, n_threads=8)
+    a = syn.aligner(capi.CI_OPTS)
+    for caps in (dict(smem_cap=512), dict(ops_cap=8192), dict(cand_cap=64), dict(smem_cap=300, cand_cap=16, ops_cap=4096)):
+        before = a.debug_set_pool_caps(**caps)
+        g = a.align_batch(bases, off)
+        assert_batch_equal(g, ref)
+        assert a.debug_set_pool_caps() > before, "the small pools did not overflow: %r" % (caps,)
+    a.close()
+    # long reads: op bytes per read far above the pool heuristic (2 * L per exonic alignment)
+    lb, lo, _ = synth.simulate_reads(chrm.t, 6000, 600, sub_rate=0.02, indel_rate=0.004, stream=78)
+    opts = dict(capi.DEFAULT_OPTS, min_aln_score_percent=0.9)
+    check_align(chrm, lb, lo, opts)
+    # seed-pool overflow on the seed-only surface
+    a = syn.aligner(capi.CI_OPTS)
+    a.debug_set_pool_caps(smem_cap=256)
+    g_off, g_mems = a.smems_batch(bases, off, 12)
+    r = syn.oix.all_smems(bases, off, 12)
+    assert np.array_equal(g_off, r.offsets) and np.array_equal(g_mems["ref_idx"], r.mems["ref_idx"])
+    a.close()

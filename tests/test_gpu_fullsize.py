@@ -68,3 +68,22 @@ def test_error_free_reads_align_end_to_end(world):
     # the transcript the read was drawn from is among the perfect exonic alignments unless an isoform ties
     assert np.all(top["tx_yend"] - top["tx_ystart"] == 91)
     a.close()
+
+
+def test_config5_shape_full_size(world):
+    """BASELINE config 5's read shape at full batch size: 500 000 reads of 150 bp with band +-64
+    (percent 0.574 -> 3 cells per lane, wide traces in global memory) against the chr21-sized text
+    (the GRCh38-sized text of config 5 is covered by the wide-coordinate tests): exact parity with
+    the oracle on every read."""
+    t, sa, ix = world
+    n = 500000
+    opts = dict(min_seed_len=20, min_aln_score_percent=0.574, min_aln_score=30, multimap_score_range=1, intron_mode=True)
+    bases, off, _ = synth.simulate_reads(t, n, 150, sub_rate=0.01, indel_rate=0.001, stream=150)
+    a = capi.Aligner(ix, opts)
+    g = a.align_batch(bases, off)
+    oix = orc.Index(t, sa=sa)
+    r = oix.align_batch(bases, off, opts, n_threads=16)
+    assert_batch_equal(g, r)
+    checked, bad = validate.check_batch(t, bases, off, g, max_alns=2000)
+    assert checked == 2000 and not bad, bad[:5]
+    a.close()

@@ -209,6 +209,9 @@ def lib():
     if hasattr(L, "thm_debug_prof_get"):
         L.thm_debug_prof_get.restype = i32
         L.thm_debug_prof_get.argtypes = [vp, vp, i32]
+    if hasattr(L, "thm_debug_set_pool_caps"):
+        L.thm_debug_set_pool_caps.restype = i32
+        L.thm_debug_set_pool_caps.argtypes = [vp, u64, u64, u64, vp]
     if hasattr(L, "thm_debug_wave_prims"):
         L.thm_debug_wave_prims.restype = i32
         L.thm_debug_wave_prims.argtypes = [vp, vp, vp]
@@ -478,6 +481,12 @@ class Aligner:
         out = np.zeros(16, "<u8")
         self._chk(lib().thm_debug_prof_get(self.h, _ptr(out), int(reset)))
         return out
+
+    def debug_set_pool_caps(self, smem_cap=0, cand_cap=0, ops_cap=0):
+        """test hook: initial pool sizes for the next batches; returns the replay count so far"""
+        n = C.c_uint32()
+        self._chk(lib().thm_debug_set_pool_caps(self.h, smem_cap, cand_cap, ops_cap, C.byref(n)))
+        return n.value
 
     def debug_wave_prims(self, v):
         v = np.ascontiguousarray(v, "<i4")

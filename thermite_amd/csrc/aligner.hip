@@ -323,6 +323,18 @@ int32_t thm_debug_prof_get(thm_aligner* a, uint64_t out[16], int32_t reset) {
   return THM_OK;
 }
 
+// test hook: start the next batches with these pool sizes (entries, entries, bytes; 0 = the usual heuristics) so that
+// the grow-and-replay path of thm_batch_sync is exercised; returns the number of replays so far through *n_replays
+int32_t thm_debug_set_pool_caps(thm_aligner* a, uint64_t smem_cap, uint64_t cand_cap, uint64_t ops_cap, uint32_t* n_replays) {
+  if (!a) return THM_ERR_INVALID_ARG;
+  a->dbg_smem_cap = smem_cap;
+  a->dbg_cand_cap = cand_cap;
+  a->dbg_ops_cap = ops_cap;
+  a->smem_cap = a->cand_cap = a->cand_ops_cap = 0;
+  if (n_replays) *n_replays = a->n_replays;
+  return THM_OK;
+}
+
 // debug hook used by tests/test_gpu_swg.py: wave scan / shift primitives
 int32_t thm_debug_wave_prims(thm_aligner* a, const int32_t in[64], int32_t out[384]) {
   if (!a || !in || !out) return THM_ERR_INVALID_ARG;

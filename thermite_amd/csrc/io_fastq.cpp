@@ -9,6 +9,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,8 @@ struct thm_fastq {
   std::vector<char> buf;  // lines are handed out as views into this buffer (no per-line copies)
   size_t pos = 0, end = 0;
   bool eof = false;
+  bool io_err = false;  // a read error (not end of file): reported as THM_ERR_IO, never as a short file
+  std::string io_msg;
   uint64_t lineno = 0;
   std::string pending;  // a FASTA header read ahead while collecting sequence lines
   bool have_pending = false;
@@ -58,10 +61,28 @@ struct thm_fastq {
       if (end == buf.size()) buf.resize(buf.size() * 2);
       const size_t room = std::min<size_t>(buf.size() - end, 1u << 30);
       const long n = f ? (long)gzread(f, buf.data() + end, (unsigned)room) : (long)read(fd, buf.data() + end, room);
-      if (n <= 0)
+      if (n > 0) end += (size_t)n;
+      if (f) {
+        // a corrupt stream returns -1; a truncated one a short count and then 0 with Z_BUF_ERROR
+        if (n < (long)room) {
+          int zerr = Z_OK;
+          const char* zmsg = gzerror(f, &zerr);
+          if (n < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) {
+            io_err = true;
+            io_msg = "gzip read error in " + path + ": " + (zmsg && *zmsg ? zmsg : "corrupt or truncated stream");
+            eof = true;
+          } else if (n == 0) {
+            eof = true;
+          }
+        }
+      } else if (n < 0) {
+        if (errno == EINTR) continue;
+        io_err = true;
+        io_msg = "read error in " + path + ": " + strerror(errno);
         eof = true;
-      else
-        end += (size_t)n;
+      } else if (n == 0) {
+        eof = true;
+      }
     }
   }
 };
@@ -86,7 +107,11 @@ static inline void put(std::vector<uint8_t>& v, size_t& used, const char* p, siz
 
 int fastq_fill(thm_fastq* r, uint64_t max_reads, HostBatch& b) {
   b.clear();
-  return fastq_fill_raw(r, max_reads, b, b.nb, b.nq, b.nn);
+  const int rc = fastq_fill_raw(r, max_reads, b, b.nb, b.nq, b.nn);
+  // a read error ends the input early; whatever the parser made of the stump, the error is what is reported
+  // (needletail returns the error to align_reads_from_file, reference src/aligner.rs:52-55)
+  if (r->io_err) return fail(THM_ERR_IO, r->io_msg);
+  return rc;
 }
 
 static int fastq_fill_raw(thm_fastq* r, uint64_t max_reads, HostBatch& b, size_t& nb, size_t& nq, size_t& nn) {

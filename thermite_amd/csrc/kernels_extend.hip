@@ -425,8 +425,11 @@ __device__ unsigned long long emit_alignment(Wctx& c, const PP& p, const uint8_t
     if (lane == 0) g = atomicAdd(p.ops_cursor, (unsigned long long)grab);
     g = bcast64(g);
     if (g + grab > p.cand_ops_cap) {
+      // pool exhausted: the host grows it and replays the batch; this attempt must not leave byte
+      // counts behind that exceed what was allocated (the scans and compact_kernel still run)
       c.fault |= FAULT_OPS_POOL;
       c.pool_left = 0;
+      n_bytes = 0;
       return 0;
     }
     c.pool_off = g;
@@ -512,6 +515,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
   c.prof_last = __builtin_amdgcn_s_memtime();
 #endif
 
+  // SMEM pool overflow in the seed stage: the per-read SMEM runs are incomplete (the host grows the pool and
+  // replays the batch); nothing of them may be read
+  if (uload(p.fault_seed) != 0) return;
   auto& ix = p.ix;
   unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_reads = 0, k_opb = 0;
   unsigned k_type[3] = {0, 0, 0};  // wave-uniform (counted with ballots)
@@ -1098,6 +1104,8 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
   const int sub = (int)(threadIdx.x & 15u);
   const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   if (r >= p.n_reads) return;
+  // a faulted attempt (pool overflow) is replayed by the host with larger pools: its counts and offsets are not to be trusted
+  if (p.fault[0] != 0 || (p.fault[1] & FAULT_OPS_POOL) != 0) return;
   const uint32_t n = p.read_n_alns[r];
   if (n == 0) return;
   const uint64_t cand0 = p.read_cand_off[r];
@@ -1108,6 +1116,7 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
   const uint64_t a0 = p.read_aln_off[r];
   for (uint32_t t = 0; t < n; t++) {
     const Cand cd = cands[la[t]];
+    if (a0 + t >= p.alns_cap || o + cd.ops_len + cd.tx_ops_len > p.ops_cap) return;  // never without a fault; keeps every store in bounds
     #pragma unroll 1
     for (uint32_t b = (uint32_t)sub; b < cd.ops_len; b += 16) p.ops[o + b] = p.cand_ops[cd.ops_off + b];
     const uint64_t go = o;

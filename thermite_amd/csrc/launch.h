@@ -128,6 +128,7 @@ struct ExtendParams {
   unsigned long long* counters;
   unsigned int* queue;
   int* fault;  // bit 0: op pool overflow, bit 1: internal inconsistency, bit 2: out-of-contract (lift failure)
+  const int* fault_seed;  // set by the seed kernels on an SMEM pool overflow: the SMEM runs are incomplete, nothing may be read
   uint32_t max_read_len;
   uint32_t max_bw;
   unsigned long long* trace_scratch;  // [waves in the grid * extend_trace_scratch_bytes / 8] (unused when cpl == 1)
@@ -149,6 +150,8 @@ struct CompactParams {
   const uint64_t* read_offsets;  // read lengths
   thm_aln* alns;
   uint8_t* ops;
+  const int* fault;  // [0] seed stage, [1] extend stage: a faulted attempt is replayed by the host, nothing is compacted
+  uint64_t alns_cap, ops_cap;  // entries in alns[], bytes in ops[]
 };
 hipError_t launch_compact(const CompactParams& p, hipStream_t s);
 

@@ -49,9 +49,10 @@ int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
   HIPCHK(a, a->s_cand_off.ensure((n + 2) * 8));
   HIPCHK(a, a->scan_tmp.ensure(scan_tmp_entries(n + 1) * 8 + 64));
   // typical: 1-2 SMEMs per read; waves take the pool in 256-entry slices, hence the fixed slack
-  if (a->smem_cap < n * 4 + (4u << 20)) a->smem_cap = n * 4 + (4u << 20);
+  const uint64_t smem_min = a->dbg_smem_cap ? a->dbg_smem_cap : n * 4 + (4u << 20);
+  if (a->smem_cap < smem_min) a->smem_cap = smem_min;
   HIPCHK(a, a->s_smems.ensure(a->smem_cap * sizeof(Smem)));
-  a->smem_cap = std::max<uint64_t>(a->smem_cap, a->s_smems.cap / sizeof(Smem));
+  if (!a->dbg_smem_cap) a->smem_cap = std::max<uint64_t>(a->smem_cap, a->s_smems.cap / sizeof(Smem));
   // to_ascii_uppercase (src/aligner.rs:125) + sanitising, once per run for both kernels
   HIPCHK(a, a->r_san.ensure(a->n_bases + 256));
   HIPCHK(a, launch_sanitize(a->r_bases.as<uint8_t>(), a->r_san.as<uint8_t>(), a->n_bases, a->n_bases + 128, s));
@@ -119,8 +120,10 @@ int enqueue_run(thm_aligner* a) {
   if (rc != THM_OK) return rc;
   HIPCHK(a, hipEventRecord(a->ev[1], s));
 
-  if (a->cand_cap < n * 3 + 1024) a->cand_cap = n * 3 + 1024;
-  if (a->cand_ops_cap < n * 384 + 65536) a->cand_ops_cap = n * 384 + 65536;
+  const uint64_t cand_min = a->dbg_cand_cap ? a->dbg_cand_cap : n * 3 + 1024;
+  const uint64_t ops_min = a->dbg_ops_cap ? a->dbg_ops_cap : n * 384 + 65536;
+  if (a->cand_cap < cand_min) a->cand_cap = cand_min;
+  if (a->cand_ops_cap < ops_min) a->cand_ops_cap = ops_min;
   HIPCHK(a, a->e_cands.ensure(a->cand_cap * sizeof(Cand)));
   HIPCHK(a, a->e_order.ensure(a->cand_cap * 2 * 4));
   HIPCHK(a, a->e_ops.ensure(a->cand_ops_cap + 64));
@@ -157,6 +160,7 @@ int enqueue_run(thm_aligner* a) {
   ep.counters = a->d_counters.as<unsigned long long>();
   ep.queue = a->d_queue.as<unsigned int>();
   ep.fault = a->d_fault.as<int>() + 1;
+  ep.fault_seed = a->d_fault.as<int>();
   ep.max_read_len = a->max_read_len;
   ep.max_bw = bw_max;
   ep.prof = a->d_counters.as<unsigned long long>() + 2 * THM_N_COUNTERS;
@@ -183,6 +187,9 @@ int enqueue_run(thm_aligner* a) {
   cp.read_offsets = a->r_offsets.as<uint64_t>();
   cp.alns = a->o_alns.as<thm_aln>();
   cp.ops = a->o_ops.as<uint8_t>();
+  cp.fault = a->d_fault.as<int>();
+  cp.alns_cap = a->cand_cap;
+  cp.ops_cap = a->cand_ops_cap;
   HIPCHK(a, launch_compact(cp, s));
   HIPCHK(a, hipEventRecord(a->ev[4], s));
   return THM_OK;
@@ -258,10 +265,13 @@ int32_t thm_batch_sync(thm_aligner* a) {
     RunStatus st;
     int rc = read_status(a, &st);
     if (rc != THM_OK) return rc;
-    if (st.fault_ext & 2) return fail(a, THM_ERR_INTERNAL, "extend kernel reported an internal inconsistency");
-    if (st.fault_ext & 4)
-      return fail(a, THM_ERR_OUT_OF_CONTRACT,
-                  "a read hit a condition that panics in the reference (lift_mem_to_tx / lift_tx_to_gx)");
+    // a seed-pool overflow comes first: the extend kernel did not run on that attempt (its fault word means nothing)
+    if (!st.fault_seed) {
+      if (st.fault_ext & 2) return fail(a, THM_ERR_INTERNAL, "extend kernel reported an internal inconsistency");
+      if (st.fault_ext & 4)
+        return fail(a, THM_ERR_OUT_OF_CONTRACT,
+                    "a read hit a condition that panics in the reference (lift_mem_to_tx / lift_tx_to_gx)");
+    }
     const bool grow = st.fault_seed || (st.fault_ext & 1);
     if (!grow) {
       float ms = 0;
@@ -280,6 +290,7 @@ int32_t thm_batch_sync(thm_aligner* a) {
       return fail(a, THM_ERR_OOM, "batch has %llu seed hits: candidate pool would exceed 160 GiB", st.total_hits);
     HIPCHK(a, hipMemcpyAsync(a->d_counters.p, a->d_counters.as<uint8_t>() + THM_N_COUNTERS * 8, THM_N_COUNTERS * 8,
                              hipMemcpyDeviceToDevice, a->stream));
+    a->n_replays++;
     rc = enqueue_run(a);
     if (rc != THM_OK) return rc;
   }
@@ -350,6 +361,7 @@ int32_t thm_smems_batch(thm_aligner* a, const uint8_t* bases, const uint64_t* of
     if (rc != THM_OK) return rc;
     if (!st.fault_seed) break;
     if (attempt >= 6) return fail(a, THM_ERR_INTERNAL, "smem pool kept overflowing");
+    a->n_replays++;
     a->smem_cap = std::max<uint64_t>(a->smem_cap * 2, st.smem_used + 1024);
   }
   a->uploaded = false;  // the seed-only pass leaves no aligned batch behind
