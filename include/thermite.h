@@ -156,6 +156,15 @@ typedef struct thm_batch_view {
   const uint64_t* read_aln_off; /* [n_reads+1] */
   const thm_aln* alns;          /* [n_alns]    */
   const uint8_t* ops;           /* [n_op_bytes] */
+  /* Per-read status.  The reference aligns a read of any length with a band of any width
+   * (src/swg.rs:17-26, src/aligner.rs:137-141) and panics on a few inconsistent inputs; one such read must not
+   * fail the other reads of its batch, so those outcomes are reported per read: n_failed_reads counts the
+   * reads whose status is not THM_OK (they have no alignments), read_status is NULL when there are none,
+   * else [n_reads] of THM_OK, THM_ERR_UNSUPPORTED (read longer than 65535 bases, or a band whose DP trace
+   * exceeds the device-memory budget) or THM_ERR_OUT_OF_CONTRACT (a condition that panics in the reference:
+   * lift_mem_to_tx / lift_tx_to_gx, src/txome.rs:102,154). */
+  uint64_t n_failed_reads;
+  const int32_t* read_status;
 } thm_batch_view;
 
 /* Result of thm_smems_batch: mems of read r in Index::all_smems order. */
@@ -229,16 +238,34 @@ int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_re
                                    const uint8_t* tx_seq, uint64_t n_tx_seq, const thm_span* genes,
                                    uint32_t n_genes, const uint32_t* name_rank, uint32_t n_names,
                                    const uint32_t* sa, thm_index** out);
+/* The same with a coordinate-width choice.  The reference keeps every text position and suffix-array rank in a
+ * usize (src/index.rs:364-388: divsufsort64 -> Vec<usize>; Mem{ref_idx: usize}); a GRCh38-2020-A text has
+ * about 6.2 G symbols.  The library holds the index either with 32-bit positions and ranks (text below 2^31
+ * symbols; the default, half the bytes) or with 64-bit ones (any text; chosen automatically from `n`, or forced
+ * by THM_INDEX_WIDE in `flags` or THM_FORCE_WIDE=1 in the environment, which runs the wide code path on small
+ * texts).  Results do not depend on the width.  `sa` may be NULL or a suffix array with `sa_elem_bytes` = 4 or
+ * 8 bytes per entry (checked, converted to the index's width). */
+#define THM_INDEX_WIDE 1u
+int32_t thm_index_create_in_memory_ex(const uint8_t* text, uint64_t n, const thm_ref* refs, uint32_t n_refs,
+                                      const thm_tx* txs, uint32_t n_txs, const thm_exon* exons, uint64_t n_exons,
+                                      const uint8_t* tx_seq, uint64_t n_tx_seq, const thm_span* genes,
+                                      uint32_t n_genes, const uint32_t* name_rank, uint32_t n_names, const void* sa,
+                                      uint32_t sa_elem_bytes, uint32_t flags, thm_index** out);
 void thm_index_free(thm_index*);
-/* number of text symbols, suffix-array pointer (host copy, n entries) */
+/* number of text symbols; bytes per text position / rank inside the index (4 or 8); suffix-array pointer
+ * (host copy, n entries) in the index's width: the other accessor returns NULL */
 uint64_t thm_index_text_len(const thm_index*);
+uint32_t thm_index_coord_bytes(const thm_index*);
 const uint32_t* thm_index_suffix_array(const thm_index*);
+const uint64_t* thm_index_suffix_array64(const thm_index*);
 /* Index::idx_to_ref, src/index.rs:287-290: returns ref index, writes offset */
 int32_t thm_index_idx_to_ref(const thm_index*, uint64_t idx, uint64_t* offset);
 
 /* host-side index construction helper (offline; src/index.rs:103-105 uses
  * libdivsufsort): suffix array of `text` by induced sorting */
 int32_t thm_build_suffix_array(const uint8_t* text, uint64_t n, uint32_t* sa_out);
+/* the same with 64-bit entries, for texts of 2^31 symbols and more (src/index.rs:104: divsufsort64) */
+int32_t thm_build_suffix_array64(const uint8_t* text, uint64_t n, uint64_t* sa_out);
 
 /* ----------------------------------------------------------------- aligner */
 

@@ -15,28 +15,44 @@ TEST_OPTS = dict(min_seed_len=3, min_aln_score_percent=0.66, min_aln_score=0, mu
 
 
 class World:
-    def __init__(self, tables):
+    def __init__(self, tables, wide=False):
         self.t = tables
-        self.ix = capi.Index(tables)
+        self.ix = capi.Index(tables, wide=wide)
+        assert self.ix.coord_bytes == (8 if wide else 4)
         self.oix = orc.Index(tables, sa=self.ix.suffix_array())
 
     def aligner(self, opts):
         return capi.Aligner(self.ix, opts)
 
 
-@pytest.fixture(scope="module")
-def test_ref(data_dir):
-    return World(refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf"))
+# Every test of this file runs twice: on an index with 32-bit text positions and ranks (c32, the default for texts
+# below 2^31 symbols) and on one with 64-bit ones (c64: the code path a GRCh38-sized text takes -- BASELINE
+# config 5's reference, reference src/index.rs:364-388 -- forced here on small texts).  Results must not
+# depend on the width.
+WIDTHS = pytest.mark.parametrize("wide", [False, True], ids=["c32", "c64"])
+_worlds = {}
 
 
-@pytest.fixture(scope="module")
-def chrm(data_dir):
-    return World(refdata.load_reference(data_dir + "/GRCh38-2020-A-chrM.fasta", data_dir + "/GRCh38-2020-A-chrM.gtf"))
+def _world(key, make, wide):
+    if (key, wide) not in _worlds:
+        _worlds[(key, wide)] = World(make(), wide)
+    return _worlds[(key, wide)]
 
 
-@pytest.fixture(scope="module")
-def syn():
-    return World(synth.synth_reference(length=400000, n_genes=40))
+@pytest.fixture(params=[False, True], ids=["c32", "c64"])
+def test_ref(request, data_dir):
+    return _world("test_ref", lambda: refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf"), request.param)
+
+
+@pytest.fixture(params=[False, True], ids=["c32", "c64"])
+def chrm(request, data_dir):
+    return _world("chrm", lambda: refdata.load_reference(data_dir + "/GRCh38-2020-A-chrM.fasta", data_dir + "/GRCh38-2020-A-chrM.gtf"),
+                  request.param)
+
+
+@pytest.fixture(params=[False, True], ids=["c32", "c64"])
+def syn(request):
+    return _world("syn", lambda: synth.synth_reference(length=400000, n_genes=40), request.param)
 
 
 def check_smems(w, bases, off, k):
@@ -56,6 +72,7 @@ def check_align(w, bases, off, opts, n_threads=8):
     g = a.align_batch(bases, off)
     r = w.oix.align_batch(bases, off, opts, n_threads=n_threads)
     assert r.counters[15] == 0, "oracle saw reads where the reference would panic"
+    assert g.n_failed == 0 and g.status is None
     assert_batch_equal(g, r)
     c = a.counters()
     assert np.array_equal(c[:10], r.counters[:10]) and c[12] == r.counters[12], (c[:13], r.counters[:13])
@@ -257,4 +274,76 @@ def test_pool_overflow_replay(syn, chrm):
     g_off, g_mems = a.smems_batch(bases, off, 12)
     r = syn.oix.all_smems(bases, off, 12)
     assert np.array_equal(g_off, r.offsets) and np.array_equal(g_mems["ref_idx"], r.mems["ref_idx"])
+    a.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# reads the register-resident kernels cannot hold: the reference takes any read length and any band
+# (src/swg.rs:17-38, src/aligner.rs:137-141); here they run in the any-width kernel, in the same batch
+def test_mixed_batch_short_and_long_reads(syn):
+    """91 bp reads with a few 300-1000 bp reads among them, the reference's chr21 flags (-k20 -s0 --intron-mode:
+    band = L - 30, i.e. +-270 .. +-970 for the long ones)"""
+    rng = np.random.default_rng(41)
+    bases, off, _ = synth.simulate_reads(syn.t, 3000, 91, sub_rate=0.01, indel_rate=0.001, intronic_frac=0.2, stream=51)
+    reads = [bases[off[i]: off[i + 1]] for i in range(3000)]
+    long_len = [300, 333, 450, 512, 640, 777, 1000, 1000]
+    for j, L in enumerate(long_len):
+        lb, lo, _ = synth.simulate_reads(syn.t, 3, L, sub_rate=0.02, indel_rate=0.004, intronic_frac=0.5, stream=60 + j)
+        for i in range(3):
+            reads.insert(int(rng.integers(0, len(reads) + 1)), lb[lo[i]: lo[i + 1]])
+    b2, o2 = refdata.pack_reads(reads)
+    check_smems(syn, b2, o2, 20)
+    g = check_align(syn, b2, o2, capi.CI_OPTS)
+    lens = np.diff(o2.astype(np.int64))
+    n_alns = np.diff(g.offsets.astype(np.int64))
+    assert (n_alns[lens > 255] > 0).sum() >= 12  # the long reads do align
+    check_align(syn, b2, o2, capi.DEFAULT_OPTS)
+
+
+def test_all_long_reads_low_threshold(syn):
+    """every read beyond the fast kernels' band (+-127): 200 and 260 bp with -s0 (bw 170 / 230), ragged"""
+    rng = np.random.default_rng(43)
+    for L in (200, 260):
+        bases, off, _ = synth.simulate_reads(syn.t, 600, L, sub_rate=0.03, indel_rate=0.006, intronic_frac=0.25, stream=70 + L)
+        reads = [bases[off[i]: off[i] + (L if i % 4 else int(rng.integers(0, L + 1)))] for i in range(600)]
+        b2, o2 = refdata.pack_reads(reads)
+        check_align(syn, b2, o2, capi.CI_OPTS)
+
+
+def test_very_long_reads(chrm):
+    """reads of 2 000 - 6 000 bases (seed-selection lists in global memory, band tiles, default and low thresholds)"""
+    from gpu_common import mutate
+    rng = np.random.default_rng(47)
+    reads = []
+    fwd = chrm.t["text"][: int(chrm.t["refs"][0]["len"])]
+    for L in (2000, 3500, 6000):
+        for flip in (False, True):  # genomic windows (chrM's transcripts are shorter), mutated, either strand
+            s0 = int(rng.integers(0, len(fwd) - L))
+            r = mutate(rng, fwd[s0: s0 + L], sub=0.02, indel=0.004)
+            reads.append(refdata.revcomp(r) if flip else r)
+    sb, so, _ = synth.simulate_reads(chrm.t, 500, 91, stream=99)
+    reads += [sb[so[i]: so[i + 1]] for i in range(500)]
+    b2, o2 = refdata.pack_reads(reads)
+    check_smems(chrm, b2, o2, 20)
+    check_align(chrm, b2, o2, capi.DEFAULT_OPTS)
+    check_align(chrm, b2, o2, dict(capi.CI_OPTS, min_aln_score_percent=0.5))
+
+
+def test_reads_beyond_every_class_get_a_status(chrm):
+    """a read longer than 65535 bases fails alone (per-read status), not the batch"""
+    sb, so, _ = synth.simulate_reads(chrm.t, 200, 91, stream=101)
+    reads = [sb[so[i]: so[i + 1]] for i in range(200)]
+    big = np.frombuffer(b"ACGT" * 17000, np.uint8)  # 68 000 bases
+    reads.insert(77, big)
+    b2, o2 = refdata.pack_reads(reads)
+    a = chrm.aligner(capi.CI_OPTS)
+    g = a.align_batch(b2, o2)
+    assert g.n_failed == 1 and g.status is not None
+    assert g.status[77] == capi.ERR_UNSUPPORTED and (np.delete(g.status, 77) == 0).all()
+    assert g.offsets[78] == g.offsets[77]
+    keep = [r for i, r in enumerate(reads) if i != 77]
+    b3, o3 = refdata.pack_reads(keep)
+    ref = chrm.oix.align_batch(b3, o3, capi.CI_OPTS, n_threads=4)
+    assert np.array_equal(np.delete(np.diff(g.offsets.astype(np.int64)), 77), np.diff(ref.offsets.astype(np.int64)))
+    assert np.array_equal(g.alns["score"], ref.alns["score"]) and np.array_equal(g.ops, ref.ops)
     a.close()

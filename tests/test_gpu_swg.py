@@ -78,6 +78,23 @@ def test_fuzz_vs_oracle(aligner, bw_lo, bw_hi, max_len, n):
     assert c[9] == ref.counters[9] and c[10] <= ref.counters[10] and c[11] <= ref.counters[11]
 
 
+@pytest.mark.parametrize("bw_lo,bw_hi,max_len,n", [(128, 200, 260, 300), (0, 700, 700, 200), (300, 1000, 1200, 60),
+                                                   (63, 64, 120, 400), (127, 129, 300, 300)])
+def test_fuzz_any_band_width(aligner, bw_lo, bw_hi, max_len, n):
+    """bands beyond +-127 (SwgExtend::new takes any band, src/swg.rs:17-26): the tiled any-width kernel; a batch whose
+    widest band exceeds +-127 runs all of its problems there, so narrow bands are covered by it as well"""
+    rng = np.random.default_rng(bw_lo * 977 + bw_hi)
+    xb, xo, yb, yo, bw, xd = swg_fuzz_problems(rng, n, max_len, bw_lo, bw_hi)
+    if bw_lo == 0:
+        bw[: n // 2] = rng.integers(0, 40, n // 2)  # many narrow problems inside the wide batch
+        xd = np.maximum(xd, bw.astype("<i4"))
+        bw[-1] = bw_hi
+        xd[-1] = bw_hi
+    alns, ops = aligner.swg_extend_batch(xb, xo, yb, yo, bw, xd, bw_hi)
+    ref = orc.swg_extend_batch(xb, xo, yb, yo, bw, xd, bw_hi)
+    assert_swg_equal(alns, ops, ref)
+
+
 def test_empty_inputs(aligner):
     xs = [b"", b"ACG", b"", b"A"]
     ys = [b"ACGT", b"", b"", b"A"]

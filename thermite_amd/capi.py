@@ -83,7 +83,8 @@ CI_OPTS = dict(min_seed_len=20, min_aln_score_percent=0.0, min_aln_score=30, mul
 
 class BatchView(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_alns", C.c_uint64), ("n_op_bytes", C.c_uint64),
-                ("read_aln_off", C.c_void_p), ("alns", C.c_void_p), ("ops", C.c_void_p)]
+                ("read_aln_off", C.c_void_p), ("alns", C.c_void_p), ("ops", C.c_void_p),
+                ("n_failed_reads", C.c_uint64), ("read_status", C.c_void_p)]
 
 
 class MemsView(C.Structure):
@@ -102,6 +103,7 @@ ABI_SYMBOLS = [
     "thm_batch_sync", "thm_batch_fetch", "thm_smems_batch", "thm_swg_extend_batch", "thm_counters_get",
     "thm_counters_reset", "thm_counters_device_ptr", "thm_timings_get", "thm_version", "thm_device_count",
     "thm_aligner_index", "thm_comm_unique_id", "thm_comm_create", "thm_comm_free", "thm_counters_allreduce",
+    "thm_index_create_in_memory_ex", "thm_index_coord_bytes", "thm_index_suffix_array64", "thm_build_suffix_array64",
 ]
 # every symbol include/thermite_io.h declares
 IO_ABI_SYMBOLS = [
@@ -127,6 +129,17 @@ def lib():
     vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
     L.thm_index_create_in_memory.restype = i32
     L.thm_index_create_in_memory.argtypes = [vp, u64, vp, u32, vp, u32, vp, u64, vp, u64, vp, u32, vp, u32, vp, vp]
+    L.thm_index_create_in_memory_ex.restype = i32
+    L.thm_index_create_in_memory_ex.argtypes = [vp, u64, vp, u32, vp, u32, vp, u64, vp, u64, vp, u32, vp, u32, vp, u32, u32, vp]
+    L.thm_index_coord_bytes.restype = u32
+    L.thm_index_coord_bytes.argtypes = [vp]
+    L.thm_index_suffix_array64.restype = vp
+    L.thm_index_suffix_array64.argtypes = [vp]
+    L.thm_build_suffix_array64.restype = i32
+    L.thm_build_suffix_array64.argtypes = [vp, u64, vp]
+    if hasattr(L, "thm_debug_check_lut"):
+        L.thm_debug_check_lut.restype = i32
+        L.thm_debug_check_lut.argtypes = [vp]
     L.thm_index_free.argtypes = [vp]
     L.thm_index_text_len.restype = u64
     L.thm_index_text_len.argtypes = [vp]
@@ -237,13 +250,18 @@ def _u8(b):
     return np.frombuffer(bytes(b), np.uint8)
 
 
-def build_suffix_array(text):
+def build_suffix_array(text, wide=False):
+    """suffix array of `text`: u32 entries, or u64 (`wide`, any text length)"""
     t = _u8(text)
-    sa = np.zeros(len(t), "<u4")
-    rc = lib().thm_build_suffix_array(_ptr(t), len(t), _ptr(sa))
+    sa = np.zeros(len(t), "<u8" if wide else "<u4")
+    f = lib().thm_build_suffix_array64 if wide else lib().thm_build_suffix_array
+    rc = f(_ptr(t), len(t), _ptr(sa))
     if rc != 0:
         raise ThermiteError(rc, "thm_build_suffix_array")
     return sa
+
+
+INDEX_WIDE = 1
 
 
 class TablesView(C.Structure):
@@ -341,15 +359,20 @@ class Index:
             tx_ids=dec(L.thm_index_tx_id, v.n_txs) if have else [],
         )
 
-    def __init__(self, tables, sa=None):
+    def __init__(self, tables, sa=None, wide=False):
+        """`wide`: 64-bit text positions and ranks inside the index even for a small text (a text of 2^31
+        symbols or more is wide by itself; THM_FORCE_WIDE=1 in the environment forces it for every index)"""
         t = tables
         self.tables = t
         h = C.c_void_p()
-        sa_arr = None if sa is None else np.ascontiguousarray(sa, "<u4")
-        rc = lib().thm_index_create_in_memory(
+        sa_arr, sa_bytes = None, 0
+        if sa is not None:
+            sa_bytes = 8 if np.asarray(sa).dtype.itemsize == 8 else 4
+            sa_arr = np.ascontiguousarray(sa, "<u8" if sa_bytes == 8 else "<u4")
+        rc = lib().thm_index_create_in_memory_ex(
             _ptr(t["text"]), len(t["text"]), _ptr(t["refs"]), len(t["refs"]), _ptr(t["txs"]), len(t["txs"]),
             _ptr(t["exons"]), len(t["exons"]), _ptr(t["tx_seq"]), len(t["tx_seq"]), _ptr(t["genes"]), len(t["genes"]),
-            _ptr(t["name_rank"]), len(t["name_rank"]), _ptr(sa_arr), C.byref(h),
+            _ptr(t["name_rank"]), len(t["name_rank"]), _ptr(sa_arr), sa_bytes, INDEX_WIDE if wide else 0, C.byref(h),
         )
         if rc != 0:
             raise ThermiteError(rc, (lib().thm_last_error(None) or b"").decode())
@@ -357,9 +380,19 @@ class Index:
         if t.get("names") and "tx_ids" in t:
             self.set_names(t["names"], t["tx_ids"], t["gene_ids"], t["gene_names"])
 
+    @property
+    def coord_bytes(self):
+        return lib().thm_index_coord_bytes(self.h)
+
     def suffix_array(self):
         n = lib().thm_index_text_len(self.h)
+        if self.coord_bytes == 8:
+            return _copy(lib().thm_index_suffix_array64(self.h), n, "<u8")
         return _copy(lib().thm_index_suffix_array(self.h), n, "<u4")
+
+    def check_lut(self):
+        """test hook: the k-mer table (built by counting) equals the one read off the suffix array"""
+        return lib().thm_debug_check_lut(self.h) == 0
 
     def idx_to_ref(self, idx):
         off = C.c_uint64()
@@ -385,6 +418,9 @@ class BatchResult:
         self.offsets = _copy(view.read_aln_off, view.n_reads + 1, "<u8")
         self.alns = _copy(view.alns, view.n_alns, ALN_DT)
         self.ops = _copy(view.ops, view.n_op_bytes, np.uint8)
+        self.n_failed = view.n_failed_reads
+        # per-read status (0 = ok); None when every read is ok
+        self.status = _copy(view.read_status, view.n_reads, "<i4") if view.read_status else None
 
 
 class Aligner:
@@ -603,7 +639,7 @@ class Writer:
         rb, keep = read_batch_struct(batch)
         offs = np.ascontiguousarray(result.offsets, "<u8")
         v = BatchView(len(offs) - 1, len(result.alns), len(result.ops), _ptr(offs), _ptr(result.alns),
-                      _ptr(result.ops))
+                      _ptr(result.ops), 0, None)
         t = Text()
         rc = lib().thm_writer_format_batch(self.h, C.byref(rb), C.byref(v), C.byref(t))
         if rc != 0:

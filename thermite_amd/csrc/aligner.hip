@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "aligner_internal.h"
@@ -43,9 +44,15 @@ static int get_dev_copy(thm_aligner* a) {
     auto up = [&](auto& buf, const auto& vec) {
       if (e == hipSuccess) e = upload(buf, vec, s);
     };
+    d->wide = ix->wide;
     up(d->text, ix->text);
-    up(d->sa, ix->sa);
-    up(d->lut, ix->lut);
+    if (ix->wide) {
+      up(d->sa, ix->sa64);
+      up(d->lut, ix->lut64);
+    } else {
+      up(d->sa, ix->sa);
+      up(d->lut, ix->lut);
+    }
     up(d->refs, ix->refs);
     up(d->name_rank, ix->name_rank);
     up(d->txs, ix->txs);
@@ -58,34 +65,47 @@ static int get_dev_copy(thm_aligner* a) {
     if (e == hipSuccess && !ix->tx_seq.empty())
       e = hipMemcpyAsync(d->tx_seq.as<uint8_t>() + 16, ix->tx_seq.data(), ix->tx_seq.size(), hipMemcpyHostToDevice, s);
     up(d->exon_grid_off, ix->exon_grid_off);
-    up(d->exon_grid, ix->exon_grid);
     up(d->gene_grid_off, ix->gene_grid_off);
-    up(d->gene_grid, ix->gene_grid);
+    if (ix->wide) {
+      up(d->exon_grid, ix->exon_grid64);
+      up(d->gene_grid, ix->gene_grid64);
+    } else {
+      up(d->exon_grid, ix->exon_grid);
+      up(d->gene_grid, ix->gene_grid);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
       free_dev_copy(d);
       return fail(a, e == hipErrorOutOfMemory ? THM_ERR_OOM : THM_ERR_HIP, "index upload failed: %s",
                   hipGetErrorString(e));
     }
-    DeviceIndex& v = d->view;
-    v.text = d->text.as<uint8_t>();
-    v.sa = d->sa.as<uint32_t>();
-    v.lut = d->lut.as<LutEntry>();
-    v.refs = d->refs.as<thm_ref>();
-    v.name_rank = d->name_rank.as<uint32_t>();
-    v.txs = d->txs.as<thm_tx>();
-    v.exons = d->exons.as<thm_exon>();
-    v.exon_txoff = d->exon_txoff.as<uint64_t>();
-    v.tx_seq = d->tx_seq.as<uint8_t>() + 16;
-    v.exon_grid_off = d->exon_grid_off.as<uint32_t>();
-    v.exon_grid = d->exon_grid.as<GridEntry>();
-    v.gene_grid_off = d->gene_grid_off.as<uint32_t>();
-    v.gene_grid = d->gene_grid.as<GridEntry>();
-    v.n = ix->n;
-    v.n_refs = (uint32_t)ix->refs.size();
-    v.n_txs = (uint32_t)ix->txs.size();
-    v.kt = ix->kt;
-    v.pad_ = 0;
+    auto fill_view = [&](auto& v) {
+      typedef typename std::remove_reference<decltype(v)>::type::coord_t C;
+      v.text = d->text.as<uint8_t>();
+      v.sa = d->sa.as<C>();
+      v.lut = d->lut.as<LutEntryT<C>>();
+      v.refs = d->refs.as<thm_ref>();
+      v.name_rank = d->name_rank.as<uint32_t>();
+      v.txs = d->txs.as<thm_tx>();
+      v.exons = d->exons.as<thm_exon>();
+      v.exon_txoff = d->exon_txoff.as<uint64_t>();
+      v.tx_seq = d->tx_seq.as<uint8_t>() + 16;
+      v.exon_grid_off = d->exon_grid_off.as<uint32_t>();
+      v.exon_grid = d->exon_grid.as<GridEntryT<C>>();
+      v.gene_grid_off = d->gene_grid_off.as<uint32_t>();
+      v.gene_grid = d->gene_grid.as<GridEntryT<C>>();
+      v.n = ix->n;
+      v.n_refs = (uint32_t)ix->refs.size();
+      v.n_txs = (uint32_t)ix->txs.size();
+      v.kt = ix->kt;
+      v.max_tx_exons = ix->max_tx_exons;
+    };
+    memset(&d->view, 0, sizeof d->view);
+    memset(&d->view64, 0, sizeof d->view64);
+    if (ix->wide)
+      fill_view(d->view64);
+    else
+      fill_view(d->view);
     ix->dev[a->device] = d;
   }
   a->dix = ix->dev[a->device];
@@ -163,7 +183,7 @@ void thm_aligner_free(thm_aligner* a) {
   (void)hipSetDevice(a->device);
   if (a->stream) (void)hipStreamSynchronize(a->stream);
   DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->d_cursors, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4,
-                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_cells, &a->s_work_counts, &a->s_smems, &a->s_off, &a->s_cnt,
+                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->r_status, &a->e_slow, &a->s_smems, &a->s_off, &a->s_cnt,
                  &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops, &a->e_nalns,
                  &a->e_nalns64, &a->e_opbytes, &a->e_aln_off, &a->e_ops_off, &a->e_trace, &a->o_alns, &a->o_ops, &a->o_mems};
   for (DBuf* b : all) b->release();
@@ -171,6 +191,7 @@ void thm_aligner_free(thm_aligner* a) {
     a->r_off[k].release();
     a->r_alns[k].release();
     a->r_ops[k].release();
+    a->r_stat[k].release();
   }
   for (auto& e : a->ev)
     if (e) (void)hipEventDestroy(e);
@@ -232,22 +253,25 @@ int32_t thm_swg_extend_batch(thm_aligner* a, const uint8_t* x_bases, const uint6
                   (unsigned long long)i);
     uint64_t xl = x_off[i + 1] - x_off[i], yl = y_off[i + 1] - y_off[i];
     if (x_off[i + 1] < x_off[i] || y_off[i + 1] < y_off[i]) return fail(a, THM_ERR_INVALID_ARG, "offsets not monotone");
-    if (xl > 4000 || band_width[i] > 127) return fail(a, THM_ERR_UNSUPPORTED, "x longer than 4000 or band > 127");
+    if (xl > MAX_READ_LEN || band_width[i] > 2 * MAX_READ_LEN)
+      return fail(a, THM_ERR_UNSUPPORTED, "x longer than %u or band wider than +-%u", MAX_READ_LEN, 2 * MAX_READ_LEN);
     uint64_t cols = std::min<uint64_t>(yl, xl + band_width[i] + 1);
     bw_max = std::max(bw_max, band_width[i]);
     x_max = std::max<uint32_t>(x_max, (uint32_t)xl);
     y_max = std::max<uint32_t>(y_max, (uint32_t)cols);
     ops_off[i + 1] = ops_off[i] + xl + cols + 8;
   }
-  const int cpl = (int)((2 * bw_max + 1 + 63) / 64);
+  int cpl = (int)((2 * bw_max + 1 + 63) / 64);
   SwgBatchParams p;
   p.x_cap = (x_max + 15u) & ~15u;
   p.y_cap = (y_max + 15u) & ~15u;
   if (p.x_cap == 0) p.x_cap = 16;
   if (p.y_cap == 0) p.y_cap = 16;
-  if (swg_batch_lds_bytes(p, cpl) > 64 * 1024)
-    return fail(a, THM_ERR_UNSUPPORTED, "band/lengths need %zu bytes of LDS per workgroup (limit 65536)",
-                swg_batch_lds_bytes(p, cpl));
+  p.max_bw = bw_max;
+  p.scratch = nullptr;
+  p.scratch_per_wave = 0;
+  // bands over +-127 or problems beyond the LDS budget: the any-width kernel (SwgExtend::new takes any band, src/swg.rs:17-26)
+  if (cpl > 4 || swg_batch_lds_bytes(p, cpl) > EXTEND_LDS_LIMIT) cpl = 0;
   const uint64_t xb_n = x_off[n], yb_n = y_off[n], pool = ops_off[n];
   HIPCHK(a, a->b0.ensure(xb_n + 16));
   HIPCHK(a, a->b1.ensure((n + 1) * 8));
@@ -286,7 +310,17 @@ int32_t thm_swg_extend_batch(thm_aligner* a, const uint8_t* x_bases, const uint6
     const int v = e ? atoi(e) : 4;
     return (v >= 1 && v <= 8) ? v : 4;
   }();
-  HIPCHK(a, launch_swg_batch(p, cpl, grid_blocks(a, n, 4, bpc), s));
+  int n_blocks = grid_blocks(a, n, 4, bpc);
+  if (cpl == 0) {
+    p.scratch_per_wave = (swg_batch_scratch_bytes(p) + 255) & ~255ull;
+    const uint64_t budget = 16ull << 30;
+    if (p.scratch_per_wave > budget) return fail(a, THM_ERR_UNSUPPORTED, "DP trace of %llu bytes per problem exceeds the device-memory budget",
+                                                 (unsigned long long)p.scratch_per_wave);
+    n_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_blocks, budget / p.scratch_per_wave / 4));
+    HIPCHK(a, a->e_slow.ensure((size_t)n_blocks * 4 * p.scratch_per_wave + 256));
+    p.scratch = a->e_slow.as<uint8_t>();
+  }
+  HIPCHK(a, launch_swg_batch(p, cpl, n_blocks, s));
   std::vector<thm_swg_aln> raw(n);
   std::vector<uint8_t> pool_h(pool);
   int fault = 0;

@@ -64,7 +64,9 @@ struct HBuf {
 struct thm_index::DevCopy {
   int device = -1;
   DBuf text, sa, lut, refs, name_rank, txs, exons, exon_txoff, tx_seq, exon_grid_off, exon_grid, gene_grid_off, gene_grid;
-  thm::DeviceIndex view;
+  bool wide = false;                     // which of the two views is valid (thermite_internal.h, "Coordinate width")
+  thm::DeviceIndexT<uint32_t> view;
+  thm::DeviceIndexT<uint64_t> view64;
 };
 
 inline void free_dev_copy(thm_index::DevCopy* d) {
@@ -93,14 +95,22 @@ struct thm_aligner {
 
   // ---- read-level pipeline ----
   DBuf r_bases, r_offsets, r_san;  // raw reads, offsets, upper-cased + sanitised copy (made by every run)
+  DBuf r_status;                   // per-read status (i32), zeroed by every run
   uint64_t n_reads = 0, n_bases = 0;
   uint32_t max_read_len = 0;
+  // lengths present in the batch, ascending, with their read counts (thm_batch_upload): the length classes of a
+  // run (which reads the register-resident kernels take) depend on the options, which may change between runs
+  std::vector<std::pair<uint32_t, uint64_t>> len_hist;
+  uint64_t n_over = 0;  // reads longer than MAX_READ_LEN (per-read status THM_ERR_UNSUPPORTED)
   bool uploaded = false;
   // seeds
-  DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp, s_ms_end, s_ms_lo, s_ms_hi, s_work_reads, s_work_cells, s_work_counts;
+  DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp, s_ms_end, s_ms_lo, s_ms_hi, s_work_reads, s_work_long, s_work_cells,
+      s_work_counts, s_sel_scratch, s_heavy, s_slow;
   uint64_t smem_cap = 0;
   // extension
-  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace;
+  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace, e_slow;
+  uint64_t n_slow_host = 0;     // reads of the slow class in the last enqueue (host count)
+  uint32_t fast_max_len = 0, slow_max_len = 0;
   uint64_t cand_cap = 0, cand_ops_cap = 0;
   // compacted outputs
   DBuf o_alns, o_ops, o_mems;
@@ -114,7 +124,7 @@ struct thm_aligner {
 
   // host results of the read-level path: two pinned sets used alternately, so that the view
   // thm_batch_fetch returned stays valid while the next batch is uploaded, run and fetched
-  HBuf r_off[2], r_alns[2], r_ops[2];
+  HBuf r_off[2], r_alns[2], r_ops[2], r_stat[2];
   int r_cur = 0;
   // host results of the operator- and seed-level calls
   std::vector<uint64_t> h_off;

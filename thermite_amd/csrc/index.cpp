@@ -18,7 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
+#include <type_traits>
 
 #include "thermite_internal.h"
 
@@ -35,22 +37,25 @@ const char* global_error_cstr() {
   return g_err.c_str();
 }
 
-bool verify_suffix_array(const uint8_t* text, uint64_t n, const uint32_t* sa) {
+template <class C>
+bool verify_suffix_array(const uint8_t* text, uint64_t n, const C* sa) {
   if (n == 0) return true;
-  std::vector<uint32_t> rank(n + 1, 0);  // rank[n] = 0: the empty suffix sorts first
+  std::vector<C> rank(n + 1, 0);  // rank[n] = 0: the empty suffix sorts first
   std::vector<uint8_t> seen(n, 0);
   for (uint64_t r = 0; r < n; r++) {
     if (sa[r] >= n || seen[sa[r]]) return false;
     seen[sa[r]] = 1;
-    rank[sa[r]] = (uint32_t)r + 1;
+    rank[sa[r]] = (C)r + 1;
   }
   for (uint64_t r = 0; r + 1 < n; r++) {
-    uint32_t a = sa[r], b = sa[r + 1];
+    C a = sa[r], b = sa[r + 1];
     if (text[a] > text[b]) return false;
     if (text[a] == text[b] && !(rank[a + 1] < rank[b + 1])) return false;
   }
   return true;
 }
+template bool verify_suffix_array<uint32_t>(const uint8_t*, uint64_t, const uint32_t*);
+template bool verify_suffix_array<uint64_t>(const uint8_t*, uint64_t, const uint64_t*);
 
 namespace {
 
@@ -135,8 +140,10 @@ void preorder_ranks(const std::vector<TreeNode>& nd, int32_t root, std::vector<u
   }
 }
 
+template <class C>
 void build_grid(const std::vector<TreeNode>& nd, int32_t root, uint64_t n, std::vector<uint32_t>& off,
-                std::vector<GridEntry>& entries) {
+                std::vector<GridEntryT<C>>& entries) {
+  typedef GridEntryT<C> GridEntry;
   std::vector<uint32_t> rank;
   preorder_ranks(nd, root, rank);
   const uint64_t nbins = (n >> GRID_SHIFT) + 1;
@@ -152,7 +159,7 @@ void build_grid(const std::vector<TreeNode>& nd, int32_t root, uint64_t n, std::
     const TreeNode& t = nd[x];
     if (t.end <= t.start) continue;
     for (uint64_t b = t.start >> GRID_SHIFT; b <= ((t.end - 1) >> GRID_SHIFT) && b < nbins; b++)
-      entries[fill[b]++] = GridEntry{(uint32_t)t.start, (uint32_t)t.end, t.value, (rank[x] << 8) | (uint32_t)(b & 0xff)};
+      entries[fill[b]++] = GridEntry{(C)t.start, (C)t.end, t.value, (rank[x] << 8) | (uint32_t)(b & 0xff)};
   }
   for (uint64_t b = 0; b < nbins; b++)
     std::sort(entries.begin() + off[b], entries.begin() + off[b + 1],
@@ -169,7 +176,19 @@ inline int base_code(uint8_t c) {
   }
 }
 
-void build_lut(thm_index* ix) {
+// k-mer prefix table: for every ACGT-only kt-mer c the suffix-array interval [lo, hi) of the suffixes
+// that start with it.  Built by counting, without touching the suffix array (one sequential pass over
+// the text instead of n random accesses):
+//   hi(c) - lo(c) = number of text positions where c occurs;
+//   lo(c) = number of suffixes that sort before the string c
+//         = (occurrences of codes < c) + (suffixes whose first kt symbols are not all ACGT and that
+//           sort before c).
+// A suffix of the second kind reads u x ..., u = m < kt ACGT symbols, x outside ACGT ('$', 'N', or the
+// end of the text): in byte order it sorts before exactly the codes c >= T, where T = u followed by the
+// smallest ACGT letter above x and then A's (x above 'T': the first code after the block that starts
+// with u).  So one difference array over the codes, filled in the same pass, gives the second term.
+template <class C>
+void build_lut(thm_index* ix, std::vector<LutEntryT<C>>& lut) {
   const uint64_t n = ix->n;
   uint32_t kt = 1;
   // about one suffix per occupied bucket: 4^kt <= 4n, at most 14 (2 GiB of 8-byte entries)
@@ -180,33 +199,95 @@ void build_lut(thm_index* ix) {
   }
   ix->kt = kt;
   const uint64_t nk = 1ull << (2 * kt);
-  ix->lut.assign(nk, LutEntry{0, 0});
-  // code_at[p] = 2-bit code of text[p..p+kt) or 0xFFFFFFFF if it is not all-ACGT
-  std::vector<uint32_t> code_at(n, 0xFFFFFFFFu);
+  // counted in place: lut[c].hi = occurrences of c, lut[c].lo = suffixes of the second kind with threshold c
+  // (a threshold past the last code precedes nothing and is dropped)
+  lut.assign(nk, LutEntryT<C>{0, 0});
+  auto dirty_at = [&](uint64_t T) {
+    if (T < nk) lut[T].lo++;
+  };
+  const uint8_t* text = ix->text.data();
+  // the text is cut into maximal ACGT runs [a, b) (b = first position outside ACGT, or n); each run is handled on its own
   {
-    uint64_t code = 0;
-    uint32_t run = 0;  // number of valid bases ending at p
-    const uint64_t mask = nk - 1;
-    for (uint64_t p = 0; p < n; p++) {
-      int c = base_code(ix->text[p]);
-      if (c < 0) {
-        run = 0;
-        code = 0;
-      } else {
-        code = ((code << 2) | (uint64_t)c) & mask;
-        if (run < kt) run++;
+    uint64_t a = 0;
+    while (a < n) {
+      if (base_code(text[a]) < 0) {  // a suffix that starts outside ACGT: m = 0, u empty, x = text[a]
+        const uint8_t x = text[a];
+        const uint64_t T = x < 'A' ? 0 : x < 'C' ? (1ull << (2 * (kt - 1))) : x < 'G' ? (2ull << (2 * (kt - 1)))
+                           : x < 'T' ? (3ull << (2 * (kt - 1))) : nk;
+        dirty_at(T);
+        a++;
+        continue;
       }
-      if (run >= kt) code_at[p + 1 - kt] = (uint32_t)code;
+      uint64_t b = a;
+      while (b < n && base_code(text[b]) >= 0) b++;
+      const bool at_end = b >= n;
+      const uint8_t x = at_end ? 0 : text[b];  // end of text: smaller than every symbol
+      // rolling code over the run
+      uint64_t code = 0;
+      const uint64_t mask = nk - 1;
+      for (uint64_t p = a; p < b; p++) {
+        code = ((code << 2) | (uint64_t)base_code(text[p])) & mask;
+        if (p + 1 - a >= kt) lut[code].hi++;  // the kt-mer starting at p + 1 - kt
+      }
+      // the last min(kt - 1, b - a) positions of the run start a suffix with m < kt ACGT symbols
+      const uint64_t first_dirty = (b - a >= kt) ? b - (kt - 1) : a;
+      for (uint64_t p = first_dirty; p < b; p++) {
+        const uint32_t m = (uint32_t)(b - p);
+        uint64_t u = 0;
+        for (uint64_t q = p; q < b; q++) u = (u << 2) | (uint64_t)base_code(text[q]);
+        const uint32_t rest = kt - m;  // symbols of a code after u; >= 1
+        uint64_t T;
+        if (x < 'A')
+          T = u << (2 * rest);
+        else if (x < 'C')
+          T = ((u << 2) | 1) << (2 * (rest - 1));
+        else if (x < 'G')
+          T = ((u << 2) | 2) << (2 * (rest - 1));
+        else if (x < 'T')
+          T = ((u << 2) | 3) << (2 * (rest - 1));
+        else
+          T = (u + 1) << (2 * rest);
+        dirty_at(T);
+      }
+      a = b;
     }
   }
-  const uint32_t* sa = ix->sa.data();
-  for (uint64_t r = 0; r < n; r++) {
-    uint32_t c = code_at[sa[r]];
-    if (c == 0xFFFFFFFFu) continue;
-    LutEntry& e = ix->lut[c];
-    if (e.hi == 0) e.lo = (uint32_t)r;
-    e.hi = (uint32_t)r + 1;
+  uint64_t before = 0;  // suffixes that sort before code c
+  for (uint64_t c = 0; c < nk; c++) {
+    before += lut[c].lo;
+    const uint64_t occ = lut[c].hi;
+    if (occ) {
+      lut[c].lo = (C)before;
+      lut[c].hi = (C)(before + occ);
+    } else {
+      lut[c].lo = lut[c].hi = 0;
+    }
+    before += occ;
   }
+}
+
+// the same table read off the suffix array (n random accesses): the check of build_lut in the tests
+template <class C>
+bool check_lut(const thm_index* ix, const std::vector<LutEntryT<C>>& lut, const C* sa) {
+  const uint64_t n = ix->n, kt = ix->kt, nk = 1ull << (2 * kt);
+  std::vector<LutEntryT<C>> ref(nk, LutEntryT<C>{0, 0});
+  for (uint64_t r = 0; r < n; r++) {
+    const uint64_t p = sa[r];
+    if (p + kt > n) continue;
+    uint64_t code = 0;
+    bool ok = true;
+    for (uint64_t t = 0; t < kt && ok; t++) {
+      const int c = base_code(ix->text[p + t]);
+      ok = c >= 0;
+      code = (code << 2) | (uint64_t)(c & 3);
+    }
+    if (!ok) continue;
+    if (ref[code].hi == 0) ref[code].lo = (C)r;
+    ref[code].hi = (C)r + 1;
+  }
+  for (uint64_t c = 0; c < nk; c++)
+    if (ref[c].lo != lut[c].lo || ref[c].hi != lut[c].hi) return false;
+  return true;
 }
 
 }  // namespace
@@ -221,19 +302,40 @@ int32_t thm_build_suffix_array(const uint8_t* text, uint64_t n, uint32_t* sa_out
   int rc = build_suffix_array(text, n, sa_out);
   return rc == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
 }
+int32_t thm_build_suffix_array64(const uint8_t* text, uint64_t n, uint64_t* sa_out) {
+  if ((!text && n) || !sa_out) return THM_ERR_INVALID_ARG;
+  try {
+    int rc = build_suffix_array64(text, n, sa_out);
+    return rc == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
+  } catch (const std::bad_alloc&) {
+    set_global_error("out of memory building the suffix array");
+    return THM_ERR_OOM;
+  }
+}
 
-int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_ref* refs, uint32_t n_refs,
-                                   const thm_tx* txs, uint32_t n_txs, const thm_exon* exons, uint64_t n_exons,
-                                   const uint8_t* tx_seq, uint64_t n_tx_seq, const thm_span* genes, uint32_t n_genes,
-                                   const uint32_t* name_rank, uint32_t n_names, const uint32_t* sa, thm_index** out) {
+}  // extern "C"
+
+static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref* refs, uint32_t n_refs, const thm_tx* txs,
+                                 uint32_t n_txs, const thm_exon* exons, uint64_t n_exons, const uint8_t* tx_seq,
+                                 uint64_t n_tx_seq, const thm_span* genes, uint32_t n_genes, const uint32_t* name_rank,
+                                 uint32_t n_names, const void* sa, uint32_t sa_elem_bytes, uint32_t flags, thm_index** out) {
   if (!out) return THM_ERR_INVALID_ARG;
   *out = nullptr;
   if (!text || n == 0 || !refs || n_refs == 0) {
     set_global_error("thm_index_create_in_memory: empty text or refs");
     return THM_ERR_INVALID_ARG;
   }
-  if (n >= 0x7FFFFFF0ull) {
-    set_global_error("text longer than 2^31 symbols: 64-bit suffix array not built in this round");
+  if (sa && sa_elem_bytes != 4 && sa_elem_bytes != 8) {
+    set_global_error("suffix array entries must be 4 or 8 bytes");
+    return THM_ERR_INVALID_ARG;
+  }
+  // coordinate width: 64-bit positions and ranks when the text does not fit 31 bits (with room for the window
+  // arithmetic), when the caller asks for it, or when THM_FORCE_WIDE=1 (runs the wide code path on small texts)
+  bool wide = n >= 0x7FFFFFF0ull || (flags & THM_INDEX_WIDE) != 0;
+  if (const char* e = getenv("THM_FORCE_WIDE"))
+    if (atoi(e) != 0) wide = true;
+  if (n >= (1ull << 47)) {
+    set_global_error("text longer than 2^47 symbols");
     return THM_ERR_UNSUPPORTED;
   }
   if ((n_txs && (!txs || !exons)) || (n_genes && !genes) || (n_tx_seq && !tx_seq)) return THM_ERR_INVALID_ARG;
@@ -252,12 +354,18 @@ int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_re
     set_global_error("refs do not cover the text");
     return THM_ERR_INVALID_ARG;
   }
+  uint32_t max_tx_exons = 0;
   for (uint32_t t = 0; t < n_txs; t++) {
     if (txs[t].exon_begin + txs[t].n_exons > n_exons || txs[t].seq_off + txs[t].seq_len > n_tx_seq ||
         txs[t].n_exons == 0 || (n_genes && txs[t].gene_idx >= n_genes)) {
       set_global_error("transcript table out of range");
       return THM_ERR_INVALID_ARG;
     }
+    if (txs[t].seq_len >= 0x7FFF0000ull) {
+      set_global_error("transcript longer than 2^31 bases");
+      return THM_ERR_UNSUPPORTED;
+    }
+    max_tx_exons = std::max(max_tx_exons, txs[t].n_exons);
     uint64_t sum = 0;
     for (uint32_t e = 0; e < txs[t].n_exons; e++) {
       const thm_exon& x = exons[txs[t].exon_begin + e];
@@ -280,6 +388,8 @@ int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_re
 
   thm_index* ix = new thm_index();
   ix->n = n;
+  ix->wide = wide;
+  ix->max_tx_exons = max_tx_exons;
   ix->text.assign(text, text + n);
   ix->text.resize(n + 128, (uint8_t)'$');  // padding: batched 64-byte compares / 16-byte window loads may run past the end
   ix->refs.assign(refs, refs + n_refs);
@@ -299,19 +409,41 @@ int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_re
   ix->tx_seq.resize(n_tx_seq + 16, (uint8_t)'$');
   ix->genes.assign(genes, genes + n_genes);
 
-  ix->sa.resize(n);
-  if (sa) {
-    if (!verify_suffix_array(text, n, sa)) {
-      delete ix;
-      set_global_error("supplied suffix array is not the suffix array of the text");
-      return THM_ERR_INVALID_ARG;
+  // suffix array in the index's width (a supplied array is checked, and converted when its width differs)
+  auto fill_sa = [&](auto& dst) -> int {
+    typedef typename std::remove_reference<decltype(dst)>::type::value_type C;
+    dst.resize(n);
+    if (sa) {
+      if (sa_elem_bytes == sizeof(C)) {
+        memcpy(dst.data(), sa, n * sizeof(C));
+      } else if (sa_elem_bytes == 4) {
+        const uint32_t* s4 = (const uint32_t*)sa;
+        for (uint64_t i = 0; i < n; i++) dst[i] = (C)s4[i];
+      } else {
+        const uint64_t* s8 = (const uint64_t*)sa;
+        for (uint64_t i = 0; i < n; i++) {
+          if (s8[i] >= n) return THM_ERR_INVALID_ARG;
+          dst[i] = (C)s8[i];
+        }
+      }
+      if (!verify_suffix_array<C>(text, n, dst.data())) {
+        set_global_error("supplied suffix array is not the suffix array of the text");
+        return THM_ERR_INVALID_ARG;
+      }
+      return THM_OK;
     }
-    memcpy(ix->sa.data(), sa, n * sizeof(uint32_t));
-  } else if (build_suffix_array(text, n, ix->sa.data()) != 0) {
+    if (sizeof(C) == 4) return build_suffix_array(text, n, (uint32_t*)dst.data()) == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
+    return build_suffix_array64(text, n, (uint64_t*)dst.data()) == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
+  };
+  const int src = wide ? fill_sa(ix->sa64) : fill_sa(ix->sa);
+  if (src != THM_OK) {
     delete ix;
-    return THM_ERR_UNSUPPORTED;
+    return src;
   }
-  build_lut(ix);
+  if (wide)
+    build_lut<uint64_t>(ix, ix->lut64);
+  else
+    build_lut<uint32_t>(ix, ix->lut);
 
   // exon_to_tx: src/index.rs:164-191 inserts each transcript's exons in the
   // order the annotation lists them (genomic order) BEFORE reversing the
@@ -338,15 +470,70 @@ int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_re
     ix->gene_tree.swap(a.nd);
     ix->gene_root = root;
   }
-  build_grid(ix->exon_tree, ix->exon_root, n, ix->exon_grid_off, ix->exon_grid);
-  build_grid(ix->gene_tree, ix->gene_root, n, ix->gene_grid_off, ix->gene_grid);
+  if (wide) {
+    build_grid<uint64_t>(ix->exon_tree, ix->exon_root, n, ix->exon_grid_off, ix->exon_grid64);
+    build_grid<uint64_t>(ix->gene_tree, ix->gene_root, n, ix->gene_grid_off, ix->gene_grid64);
+  } else {
+    build_grid<uint32_t>(ix->exon_tree, ix->exon_root, n, ix->exon_grid_off, ix->exon_grid);
+    build_grid<uint32_t>(ix->gene_tree, ix->gene_root, n, ix->gene_grid_off, ix->gene_grid);
+  }
   ix->dev_mu = new std::mutex();
   *out = ix;
   return THM_OK;
 }
 
+// no exception leaves the C ABI: allocation failures become THM_ERR_OOM
+template <class F>
+static int32_t guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    set_global_error("out of memory");
+    return THM_ERR_OOM;
+  } catch (const std::exception& e) {
+    set_global_error(std::string("internal error: ") + e.what());
+    return THM_ERR_INTERNAL;
+  } catch (...) {
+    set_global_error("internal error");
+    return THM_ERR_INTERNAL;
+  }
+}
+
+extern "C" {
+
+int32_t thm_index_create_in_memory(const uint8_t* text, uint64_t n, const thm_ref* refs, uint32_t n_refs,
+                                   const thm_tx* txs, uint32_t n_txs, const thm_exon* exons, uint64_t n_exons,
+                                   const uint8_t* tx_seq, uint64_t n_tx_seq, const thm_span* genes, uint32_t n_genes,
+                                   const uint32_t* name_rank, uint32_t n_names, const uint32_t* sa, thm_index** out) {
+  return guarded([&] {
+    return index_create_impl(text, n, refs, n_refs, txs, n_txs, exons, n_exons, tx_seq, n_tx_seq, genes, n_genes, name_rank,
+                             n_names, sa, 4, 0, out);
+  });
+}
+
+int32_t thm_index_create_in_memory_ex(const uint8_t* text, uint64_t n, const thm_ref* refs, uint32_t n_refs,
+                                      const thm_tx* txs, uint32_t n_txs, const thm_exon* exons, uint64_t n_exons,
+                                      const uint8_t* tx_seq, uint64_t n_tx_seq, const thm_span* genes, uint32_t n_genes,
+                                      const uint32_t* name_rank, uint32_t n_names, const void* sa, uint32_t sa_elem_bytes,
+                                      uint32_t flags, thm_index** out) {
+  return guarded([&] {
+    return index_create_impl(text, n, refs, n_refs, txs, n_txs, exons, n_exons, tx_seq, n_tx_seq, genes, n_genes, name_rank,
+                             n_names, sa, sa_elem_bytes, flags, out);
+  });
+}
+
+uint32_t thm_index_coord_bytes(const thm_index* ix) { return ix ? (ix->wide ? 8u : 4u) : 0u; }
+const uint64_t* thm_index_suffix_array64(const thm_index* ix) { return (ix && ix->wide) ? ix->sa64.data() : nullptr; }
+
+// test hook: the k-mer table (built by counting) against the one read off the suffix array
+int32_t thm_debug_check_lut(const thm_index* ix) {
+  if (!ix) return THM_ERR_INVALID_ARG;
+  const bool ok = ix->wide ? check_lut<uint64_t>(ix, ix->lut64, ix->sa64.data()) : check_lut<uint32_t>(ix, ix->lut, ix->sa.data());
+  return ok ? THM_OK : THM_ERR_INTERNAL;
+}
+
 uint64_t thm_index_text_len(const thm_index* ix) { return ix ? ix->n : 0; }
-const uint32_t* thm_index_suffix_array(const thm_index* ix) { return ix ? ix->sa.data() : nullptr; }
+const uint32_t* thm_index_suffix_array(const thm_index* ix) { return (ix && !ix->wide) ? ix->sa.data() : nullptr; }
 
 // Index::idx_to_ref, src/index.rs:287-290
 int32_t thm_index_idx_to_ref(const thm_index* ix, uint64_t idx, uint64_t* offset) {

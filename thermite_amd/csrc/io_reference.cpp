@@ -218,12 +218,13 @@ uint8_t comp(uint8_t c) {
 }
 
 // ---- index container ----
-constexpr char MAGIC[8] = {'T', 'H', 'M', 'I', 'D', 'X', '0', '1'};
+constexpr char MAGIC[8] = {'T', 'H', 'M', 'I', 'D', 'X', '0', '2'};
 
 struct FileHeader {
   char magic[8];
   uint64_t n_text, n_refs, n_txs, n_exons, n_tx_seq, n_genes, n_contigs, names_bytes;
   uint64_t sizeof_ref, sizeof_tx, sizeof_exon, sizeof_span;
+  uint64_t sa_bytes;  // bytes per suffix-array entry: 4, or 8 for an index with 64-bit coordinates
   uint64_t checksum;  // FNV-1a over every byte after the header
 };
 
@@ -245,6 +246,20 @@ void pack_names(const std::vector<std::string>& v, std::string& blob) {
 
 }  // namespace
 
+// no exception leaves the C ABI (a huge or corrupt input must not terminate the host process)
+template <class F>
+static int32_t guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(THM_ERR_OOM, "out of memory");
+  } catch (const std::exception& e) {
+    return fail(THM_ERR_INTERNAL, std::string("internal error: ") + e.what());
+  } catch (...) {
+    return fail(THM_ERR_INTERNAL, "internal error");
+  }
+}
+
 extern "C" {
 
 int32_t thm_index_set_names(thm_index* ix, const char* const* contig_names, uint32_t n_contigs, const char* const* tx_ids,
@@ -262,7 +277,7 @@ int32_t thm_index_set_names(thm_index* ix, const char* const* contig_names, uint
   return THM_OK;
 }
 
-int32_t thm_index_create_from_files(const char* fasta_path, const char* gtf_path, thm_index** out) {
+static int32_t index_from_files_impl(const char* fasta_path, const char* gtf_path, thm_index** out) {
   if (!out) return THM_ERR_INVALID_ARG;
   *out = nullptr;
   if (!fasta_path || !gtf_path) return THM_ERR_INVALID_ARG;
@@ -416,7 +431,7 @@ const char* thm_index_gene_name(const thm_index* ix, uint32_t i) {
   return (ix && i < ix->gene_names.size()) ? ix->gene_names[i].c_str() : nullptr;
 }
 
-int32_t thm_index_save(const thm_index* ix, const char* path) {
+static int32_t index_save_impl(const thm_index* ix, const char* path) {
   if (!ix || !path) return THM_ERR_INVALID_ARG;
   std::string names;
   pack_names(ix->contig_names, names);
@@ -444,13 +459,14 @@ int32_t thm_index_save(const thm_index* ix, const char* path) {
   h.sizeof_tx = sizeof(thm_tx);
   h.sizeof_exon = sizeof(thm_exon);
   h.sizeof_span = sizeof(thm_span);
+  h.sa_bytes = ix->wide ? 8 : 4;
   struct Sec {
     const void* p;
     size_t n;
   };
   const uint64_t has_names = ix->contig_names.empty() ? 0 : 1;
   const Sec secs[] = {{ix->text.data(), (size_t)h.n_text},
-                      {ix->sa.data(), (size_t)h.n_text * 4},
+                      {ix->wide ? (const void*)ix->sa64.data() : (const void*)ix->sa.data(), (size_t)h.n_text * (size_t)h.sa_bytes},
                       {ix->refs.data(), (size_t)h.n_refs * sizeof(thm_ref)},
                       {rank_of_name.data(), (size_t)h.n_contigs * 4},
                       {ix->txs.data(), (size_t)h.n_txs * sizeof(thm_tx)},
@@ -471,7 +487,7 @@ int32_t thm_index_save(const thm_index* ix, const char* path) {
   return THM_OK;
 }
 
-int32_t thm_index_load(const char* path, thm_index** out) {
+static int32_t index_load_impl(const char* path, thm_index** out) {
   if (!out) return THM_ERR_INVALID_ARG;
   *out = nullptr;
   if (!path) return THM_ERR_INVALID_ARG;
@@ -482,24 +498,31 @@ int32_t thm_index_load(const char* path, thm_index** out) {
     fclose(f);
     return fail(THM_ERR_FORMAT, std::string(path) + " is not a THMIDX01 index file");
   }
-  if (h.sizeof_ref != sizeof(thm_ref) || h.sizeof_tx != sizeof(thm_tx) || h.sizeof_exon != sizeof(thm_exon) ||
-      h.sizeof_span != sizeof(thm_span) || h.n_text == 0 || h.n_text >= 0x7FFFFFF0ull || h.n_refs > 0xFFFFFFFFull ||
-      h.n_txs > 0xFFFFFFFFull || h.n_genes > 0xFFFFFFFFull || h.n_contigs > h.n_refs) {
+  fseek(f, 0, SEEK_END);
+  const uint64_t have = (uint64_t)ftell(f);
+  fseek(f, (long)sizeof h, SEEK_SET);
+  // no count may exceed the file itself (so the products below cannot wrap around)
+  const uint64_t counts[] = {h.n_text, h.n_refs, h.n_txs, h.n_exons, h.n_tx_seq, h.n_genes, h.n_contigs, h.names_bytes};
+  bool sane = h.sizeof_ref == sizeof(thm_ref) && h.sizeof_tx == sizeof(thm_tx) && h.sizeof_exon == sizeof(thm_exon) &&
+              h.sizeof_span == sizeof(thm_span) && (h.sa_bytes == 4 || h.sa_bytes == 8) && h.n_text != 0 &&
+              (h.sa_bytes == 8 || h.n_text < 0x7FFFFFF0ull) && h.n_refs <= 0xFFFFFFFFull && h.n_txs <= 0xFFFFFFFFull &&
+              h.n_genes <= 0xFFFFFFFFull && h.n_contigs <= h.n_refs;
+  for (uint64_t c : counts) sane = sane && c <= have;
+  if (!sane) {
     fclose(f);
     return fail(THM_ERR_FORMAT, std::string(path) + ": header fields out of range");
   }
   // the sizes the header announces must be what the file holds (before any allocation)
-  const uint64_t expect = sizeof h + h.n_text * 5 + h.n_refs * sizeof(thm_ref) + h.n_contigs * 4 + h.n_txs * sizeof(thm_tx) +
-                          h.n_exons * sizeof(thm_exon) + h.n_tx_seq + h.n_genes * sizeof(thm_span) + 8 + h.names_bytes;
-  fseek(f, 0, SEEK_END);
-  const uint64_t have = (uint64_t)ftell(f);
-  fseek(f, (long)sizeof h, SEEK_SET);
+  const uint64_t expect = sizeof h + h.n_text * (1 + h.sa_bytes) + h.n_refs * sizeof(thm_ref) + h.n_contigs * 4 +
+                          h.n_txs * sizeof(thm_tx) + h.n_exons * sizeof(thm_exon) + h.n_tx_seq + h.n_genes * sizeof(thm_span) + 8 +
+                          h.names_bytes;
   if (have != expect) {
     fclose(f);
     return fail(THM_ERR_FORMAT, std::string(path) + ": file size does not match its header (truncated?)");
   }
   std::vector<uint8_t> text(h.n_text), tx_seq(h.n_tx_seq);
-  std::vector<uint32_t> sa(h.n_text), rank_of_name(h.n_contigs);
+  std::vector<uint8_t> sa((size_t)h.n_text * (size_t)h.sa_bytes);
+  std::vector<uint32_t> rank_of_name(h.n_contigs);
   std::vector<thm_ref> refs(h.n_refs);
   std::vector<thm_tx> txs(h.n_txs);
   std::vector<thm_exon> exons(h.n_exons);
@@ -514,7 +537,7 @@ int32_t thm_index_load(const char* path, thm_index** out) {
     if (ok) ck = fnv1a(ck, p, n);
   };
   rd(text.data(), text.size());
-  rd(sa.data(), sa.size() * 4);
+  rd(sa.data(), sa.size());
   rd(refs.data(), refs.size() * sizeof(thm_ref));
   rd(rank_of_name.data(), rank_of_name.size() * 4);
   rd(txs.data(), txs.size() * sizeof(thm_tx));
@@ -527,9 +550,10 @@ int32_t thm_index_load(const char* path, thm_index** out) {
   if (!ok) return fail(THM_ERR_IO, std::string("short read from ") + path);
   if (ck != h.checksum) return fail(THM_ERR_FORMAT, std::string(path) + ": checksum mismatch");
   thm_index* ix = nullptr;
-  int rc = thm_index_create_in_memory(text.data(), h.n_text, refs.data(), (uint32_t)h.n_refs, txs.data(), (uint32_t)h.n_txs,
-                                      exons.data(), h.n_exons, tx_seq.data(), h.n_tx_seq, genes.data(), (uint32_t)h.n_genes,
-                                      rank_of_name.data(), (uint32_t)h.n_contigs, sa.data(), &ix);
+  int rc = thm_index_create_in_memory_ex(text.data(), h.n_text, refs.data(), (uint32_t)h.n_refs, txs.data(), (uint32_t)h.n_txs,
+                                         exons.data(), h.n_exons, tx_seq.data(), h.n_tx_seq, genes.data(), (uint32_t)h.n_genes,
+                                         rank_of_name.data(), (uint32_t)h.n_contigs, sa.data(), (uint32_t)h.sa_bytes,
+                                         h.sa_bytes == 8 ? THM_INDEX_WIDE : 0u, &ix);
   if (rc != THM_OK) return rc;
   if (has_names) {
     std::vector<std::string> all;
@@ -556,6 +580,16 @@ int32_t thm_index_load(const char* path, thm_index** out) {
   }
   *out = ix;
   return THM_OK;
+}
+
+int32_t thm_index_create_from_files(const char* fasta_path, const char* gtf_path, thm_index** out) {
+  return guarded([&] { return index_from_files_impl(fasta_path, gtf_path, out); });
+}
+int32_t thm_index_save(const thm_index* ix, const char* path) {
+  return guarded([&] { return index_save_impl(ix, path); });
+}
+int32_t thm_index_load(const char* path, thm_index** out) {
+  return guarded([&] { return index_load_impl(path, out); });
 }
 
 }  // extern "C"

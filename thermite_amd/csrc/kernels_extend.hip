@@ -29,45 +29,65 @@
 namespace thm {
 namespace dev {
 
-constexpr int MAX_YCLIPS = 64;
-enum : int { FAULT_OPS_POOL = 1, FAULT_INTERNAL = 2, FAULT_CONTRACT = 4 };
+// FAULT_OPS_POOL / FAULT_INTERNAL go to the batch's fault word; FAULT_CONTRACT (a condition that panics in the
+// reference) and FAULT_RETRY (more introns in one alignment than the fast kernel's marker list holds) are per read
+enum : int { FAULT_OPS_POOL = 1, FAULT_INTERNAL = 2, FAULT_CONTRACT = 4, FAULT_RETRY = 8 };
+
+// signed type that holds a text coordinate of width C and small negative offsets from it
+template <class C>
+struct CoordTraits {
+  typedef int S;
+};
+template <>
+struct CoordTraits<uint64_t> {
+  typedef long long S;
+};
+__device__ __forceinline__ uint32_t readlane_c(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t readlane_c(uint64_t v, int l) {
+  return ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffu), l);
+}
 
 __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
   return ((unsigned long long)(unsigned)bcast_first((int)(v >> 32)) << 32) | (unsigned)bcast_first((int)(v & 0xffffffffu));
 }
 __device__ __forceinline__ void wfence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
-struct RefInfo {
-  uint32_t start, end, len;  // text < 2^31 symbols in this build: 32-bit coordinates keep the scalar unit usable
+template <class C>
+struct RefInfoT {
+  C start, end, len;  // C = uint32_t (text below 2^31 symbols) keeps this arithmetic on the 32-bit scalar unit
   uint32_t id;
   uint32_t name_rank;
   bool strand;
 };
 // Index::idx_to_ref: refs.partition_point(|x| x.end_idx <= idx)
-template <class IX>
-__device__ RefInfo idx_to_ref(const IX& ix, uint32_t idx) {
+template <class C, class IX>
+__device__ RefInfoT<C> idx_to_ref(const IX& ix, C idx) {
   uint32_t lo = 0, hi = ix.n_refs;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
-    if ((uint32_t)uload(&ix.refs[mid].end_idx) <= idx)
+    if ((C)uload(&ix.refs[mid].end_idx) <= idx)
       lo = mid + 1;
     else
       hi = mid;
   }
   if (lo >= ix.n_refs) lo = ix.n_refs - 1;
   const thm_ref r = uload(&ix.refs[lo]);
-  RefInfo o;
-  o.start = (uint32_t)r.start_idx;
-  o.end = (uint32_t)r.end_idx;
-  o.len = (uint32_t)r.len;
+  RefInfoT<C> o;
+  o.start = (C)r.start_idx;
+  o.end = (C)r.end_idx;
+  o.len = (C)r.len;
   o.id = lo;
   o.name_rank = uload(&ix.name_rank[lo]);
   o.strand = r.strand != 0;
   return o;
 }
 
-// wave-private LDS carve-up
-struct Wctx {
+// wave-private buffers: LDS in the register-resident kernels, a slice of global memory in the any-width
+// kernel (GS).  Lanes exchange data through them, so every exchange is followed by wsync(): a wavefront-scope
+// fence for LDS, a workgroup-scope one (waits for the stores; same-CU L1 is coherent) for global memory.
+template <bool GS_>
+struct WctxT {
+  static constexpr bool GS = GS_;
   uint8_t* rd;   // sanitised read, zero padded
   uint8_t* win;   // window the extension reads (genome or transcript; 16-byte aligned copy)
   uint8_t* wing;  // the hit's genome window, kept while its transcripts are tried
@@ -78,6 +98,9 @@ struct Wctx {
   uint8_t* pc;
   int* mk_k;      // intron markers of the alignment being emitted: op index they precede ...
   uint32_t* ycl;  // ... and their lengths
+  int mk_cap;
+  int* dp;        // any-width kernel: column state of swg_extend_tiled (4 arrays of dp_stride ints)
+  int dp_stride;
   int L, opcap, wcap;
   unsigned cells, cols, calls, winbytes;
   int fault;
@@ -89,6 +112,13 @@ struct Wctx {
   unsigned long long prof_cols[3];
 #endif
 };
+template <class W>
+__device__ __forceinline__ void wsync(const W&) {
+  if (W::GS)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  else
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
 
 // Section timing for tuning builds (-DTHM_PROF, libthermite_amd_prof.so): every
 // mark charges the shader clocks since the previous mark to one slot.
@@ -111,22 +141,26 @@ enum { PS_SETUP = 0, PS_STAGE = 1, PS_DP = 2, PS_TRACEBACK = 3, PS_TREE = 4, PS_
 // [qs, qe) come out in IntervalTree::find order, i.e. by ascending pre-order rank.
 // Up to 64 candidate entries sit one per lane in registers; larger candidate sets
 // (dense loci) are re-read from memory on every step.
-struct GridQuery {
-  const GridEntry* ent;  // candidates [0, cnt)
+template <class C>
+struct GridQueryT {
+  const GridEntryT<C>* ent;  // candidates [0, cnt)
   uint32_t cnt;
-  uint32_t qs, qe, b0;
+  C qs, qe;
+  uint32_t b0;
   int last;     // rank of the interval yielded last (-1 before the first)
   int my_rank;  // this lane's candidate: its rank if it overlaps and is the primary copy, else -1
   uint32_t my_val;
 };
-__device__ __forceinline__ int grid_entry_rank(const GridEntry& e, uint32_t qs, uint32_t qe, uint32_t b0) {
+template <class C>
+__device__ __forceinline__ int grid_entry_rank(const GridEntryT<C>& e, C qs, C qe, uint32_t b0) {
   const bool overlap = qs < e.end && e.start < qe;
-  const uint32_t home = max(b0, e.start >> GRID_SHIFT);  // first queried bin this interval is listed in
+  const uint32_t home = max(b0, (uint32_t)(e.start >> GRID_SHIFT));  // first queried bin this interval is listed in
   const bool primary = (e.rank & 0xffu) == (home & 0xffu);
   return (overlap && primary) ? (int)(e.rank >> 8) : -1;
 }
-__device__ void grid_begin(GridQuery& g, const uint32_t* off, const GridEntry* entries, uint32_t qs, uint32_t qe) {
-  const uint32_t b0 = qs >> GRID_SHIFT, b1 = (qe > qs ? qe - 1 : qs) >> GRID_SHIFT;
+template <class C>
+__device__ void grid_begin(GridQueryT<C>& g, const uint32_t* off, const GridEntryT<C>* entries, C qs, C qe) {
+  const uint32_t b0 = (uint32_t)(qs >> GRID_SHIFT), b1 = (uint32_t)((qe > qs ? qe - 1 : qs) >> GRID_SHIFT);
   const uint32_t e0 = uload(&off[b0]), e1 = uload(&off[b1 + 1]);
   g.ent = entries + e0;
   g.cnt = e1 - e0;
@@ -137,13 +171,14 @@ __device__ void grid_begin(GridQuery& g, const uint32_t* off, const GridEntry* e
   g.my_rank = -1;
   g.my_val = 0;
   if (g.cnt <= 64 && (uint32_t)lane_id() < g.cnt) {
-    const GridEntry e = g.ent[lane_id()];
-    g.my_rank = grid_entry_rank(e, qs, qe, b0);
+    const GridEntryT<C> e = g.ent[lane_id()];
+    g.my_rank = grid_entry_rank<C>(e, qs, qe, b0);
     g.my_val = e.value;
   }
 }
 // next overlapping interval in yield order; false when exhausted
-__device__ bool grid_next(GridQuery& g, uint32_t& value) {
+template <class C>
+__device__ bool grid_next(GridQueryT<C>& g, uint32_t& value) {
   const int BIG = 0x0fffffff;
   if (g.cnt == 0) return false;
   if (g.cnt <= 64) {
@@ -163,8 +198,8 @@ __device__ bool grid_next(GridQuery& g, uint32_t& value) {
     int r = -1;
     uint32_t v = 0;
     if (i < g.cnt) {
-      const GridEntry e = g.ent[i];
-      r = grid_entry_rank(e, g.qs, g.qe, g.b0);
+      const GridEntryT<C> e = g.ent[i];
+      r = grid_entry_rank<C>(e, g.qs, g.qe, g.b0);
       v = e.value;
     }
     const int cand = (r > g.last) ? r : BIG;
@@ -181,9 +216,10 @@ __device__ bool grid_next(GridQuery& g, uint32_t& value) {
   return true;
 }
 
-struct Path {
+template <class S>
+struct PathT {
   int score, xstart, xend, nops;
-  int ystart, yend;  // in the coordinates r / lo_abs were given in
+  S ystart, yend;  // in the coordinates r / lo_abs were given in
 };
 
 // what extend_lr did for the hit's genome window, for reuse by its transcripts
@@ -198,14 +234,20 @@ struct LrMemo {
 // One SwgExtend::extend + trace.  The band slots that can ever hold a cell number
 // min(2*bw+1, |x|+1): when that fits 64 the one-cell-per-lane code is exact even
 // inside a kernel compiled for a wider band (slots >= |x|+1 are never valid), and
-// it issues half the instructions per column.
-template <int CPL>
-__device__ __forceinline__ int swg_and_trace(Wctx& c, const uint8_t* xs, int dx, int xlen, const uint8_t* ys, int dy, int ylen,
+// it issues half the instructions per column.  CPL == 0: the any-width kernel (band in
+// tiles, everything in global memory).
+template <int CPL, class W>
+__device__ __forceinline__ int swg_and_trace(W& c, const uint8_t* xs, int dx, int xlen, const uint8_t* ys, int dy, int ylen,
                                              int bw, int xd, uint8_t* ops, int stride, int max_ops, SwgResult& r) {
   int n;
-  if (CPL > 1 && min(2 * bw + 1, xlen + 1) <= 64) {
+  if constexpr (CPL == 0) {
+    r = swg_extend_tiled(xs, dx, xlen, ys, dy, ylen, bw, xd, c.trace_g, c.dp, c.dp_stride);
+    tiled_sync();
+    PROF_MARK(c, PS_DP);
+    n = swg_traceback_tiled(c.trace_g, r.xend, r.yend, bw, ops, stride, max_ops);
+  } else if (CPL > 1 && min(2 * bw + 1, xlen + 1) <= 64) {
     r = swg_extend_wave<1>(xs, dx, xlen, ys, dy, ylen, bw, xd, c.trace);
-    wfence();
+    wsync(c);
     PROF_MARK(c, PS_DP);
     n = swg_traceback_wave<1>(c.trace, r.xend, r.yend, bw, ops, stride, max_ops);
   } else if (CPL > 2 && min(2 * bw + 1, xlen + 1) <= 128) {
@@ -218,41 +260,42 @@ __device__ __forceinline__ int swg_and_trace(Wctx& c, const uint8_t* xs, int dx,
   } else {
     // more than 64 band slots: the trace (CPL * 16 bytes per column) goes to the wave's scratch in global
     // memory; the stores of lane 0 must be visible to the loads of all lanes, hence the agent-scope fence
-    unsigned long long* tr = (CPL > 1) ? c.trace_g : c.trace;
-    r = swg_extend_wave<CPL>(xs, dx, xlen, ys, dy, ylen, bw, xd, tr);
-    if (CPL > 1)
+    constexpr int K = CPL > 0 ? CPL : 1;
+    unsigned long long* tr = (K > 1) ? c.trace_g : c.trace;
+    r = swg_extend_wave<K>(xs, dx, xlen, ys, dy, ylen, bw, xd, tr);
+    if (K > 1)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     else
-      wfence();
+      wsync(c);
     PROF_MARK(c, PS_DP);
-    n = swg_traceback_wave<CPL>(tr, r.xend, r.yend, bw, ops, stride, max_ops);
+    n = swg_traceback_wave<K>(tr, r.xend, r.yend, bw, ops, stride, max_ops);
   }
-  wfence();
+  wsync(c);
   PROF_MARK(c, PS_TRACEBACK);
   return n;
 }
 
 // extend_left_right, reference src/aligner.rs:352-407.  `win` holds ref_seq bytes
 // from absolute coordinate win0; ref_seq itself spans [lo_abs, hi_abs).
-template <int CPL>
-__device__ Path extend_lr(Wctx& c, const uint8_t* win, int win0, int lo_abs, int hi_abs, int r, int q, int len, int bw, int xd,
-                          uint8_t* buf, LrMemo& memo) {
+template <int CPL, class S, class W>
+__device__ PathT<S> extend_lr(W& c, const uint8_t* win, S win0, S lo_abs, S hi_abs, S r, int q, int len, int bw, int xd,
+                              uint8_t* buf, LrMemo& memo) {
   const int L = c.L;
-  Path p;
+  PathT<S> p;
   PROF_MARK(c, PS_OTHER);
   // right: x = read[q+len..], y = ref_seq[r+len..]   (:360-362)
   const int xr = L - (q + len);
-  const int yr_avail = hi_abs - (r + len);
-  const int yr = min(yr_avail, xr + bw + 1);
+  const S yr_avail = hi_abs - (r + len);
+  const int yr = (int)min(yr_avail, (S)(xr + bw + 1));
   SwgResult R, Lt;
-  int nr = swg_and_trace<CPL>(c, c.rd + q + len, 1, xr, win + (r + len - win0), 1, yr, bw, xd, buf + c.opcap - 1, -1,
+  int nr = swg_and_trace<CPL>(c, c.rd + q + len, 1, xr, win + (int)(r + len - win0), 1, yr, bw, xd, buf + c.opcap - 1, -1,
                               c.opcap, R);
   // left: both reversed, y = ref_seq[r.saturating_sub(L+bw)..r]   (:364-375)
   const int xl = q;
-  const int rel = r - lo_abs;
-  const int y0 = lo_abs + (rel > L + bw ? rel - (L + bw) : 0);
-  const int yl = min(r - y0, xl + bw + 1);
-  int nl = swg_and_trace<CPL>(c, c.rd + q - 1, -1, xl, win + (r - 1 - win0), -1, yl, bw, xd, buf, 1,
+  const S rel = r - lo_abs;
+  const S y0 = lo_abs + (rel > L + bw ? rel - (L + bw) : (S)0);
+  const int yl = (int)min(r - y0, (S)(xl + bw + 1));
+  int nl = swg_and_trace<CPL>(c, c.rd + q - 1, -1, xl, win + (int)(r - 1 - win0), -1, yl, bw, xd, buf, 1,
                               c.opcap - max(nr, 0), Lt);
   c.cells += R.cells + Lt.cells;
   c.cols += R.cols + Lt.cols;
@@ -279,9 +322,9 @@ __device__ Path extend_lr(Wctx& c, const uint8_t* win, int win0, int lo_abs, int
     const int t = t0 + lane;
     uint8_t v = 0;
     if (t < nr) v = buf[c.opcap - nr + t];
-    wfence();
+    wsync(c);
     if (t < nr) buf[nl + len + t] = v;
-    wfence();
+    wsync(c);
   }
   PROF_MARK(c, PS_TRACEBACK);
   memo.R = R;
@@ -290,8 +333,8 @@ __device__ Path extend_lr(Wctx& c, const uint8_t* win, int win0, int lo_abs, int
   memo.nl = nl;
   memo.yr = yr;
   memo.yl = yl;
-  memo.yoff_r = r + len - win0;
-  memo.yoff_l = r - 1 - win0;
+  memo.yoff_r = (int)(r + len - win0);
+  memo.yoff_l = (int)(r - 1 - win0);
   p.nops = nl + len + nr;
   p.score = Lt.score + len * MATCH_SCORE + R.score;
   p.ystart = r - Lt.yend;
@@ -304,7 +347,8 @@ __device__ Path extend_lr(Wctx& c, const uint8_t* win, int win0, int lo_abs, int
 // Stage [a, b) of a global byte array into c.win with 16-byte loads.  Returns the
 // coordinate that c.win[0] corresponds to (a rounded down to the 16-byte grid of
 // the source address; the arrays carry 16 bytes of padding at both ends of use).
-__device__ int stage_window(Wctx& c, uint8_t* dst, const uint8_t* src, int a, int b) {
+template <class W>
+__device__ int stage_window(W& c, uint8_t* dst, const uint8_t* src, int a, int b) {
   const unsigned mis = (unsigned)((uintptr_t)(src + a) & 15u);
   const int n = (b - a) + (int)mis;
   if (n > c.wcap) {
@@ -315,7 +359,7 @@ __device__ int stage_window(Wctx& c, uint8_t* dst, const uint8_t* src, int a, in
   uint4* w = (uint4*)dst;
   for (int t = lane_id(); t * 16 < n; t += 64) w[t] = g[t];
   c.winbytes += (unsigned)(b - a);
-  wfence();
+  wsync(c);
   PROF_MARK(c, PS_STAGE);
   return a - (int)mis;
 }
@@ -328,9 +372,9 @@ __device__ int stage_window(Wctx& c, uint8_t* dst, const uint8_t* src, int a, in
 // includes a trailing Xclip when the read is clipped on the right, which gets its
 // own loop iteration -- so an alignment that ends exactly on an exon boundary
 // still receives the intron (the edge case noted at src/txome.rs:132).
-template <class IX>
-__device__ int lift_markers(Wctx& c, const IX& ix, const thm_tx& tx, const uint8_t* path, int n, bool trailing_clip,
-                            int ystart, int yend, int& gx_ystart, int& gx_yend) {
+template <class S, class W, class IX>
+__device__ int lift_markers(W& c, const IX& ix, const thm_tx& tx, const uint8_t* path, int n, bool trailing_clip,
+                            int ystart, int yend, S& gx_ystart, S& gx_yend) {
   const thm_exon* ex = ix.exons + tx.exon_begin;
   const uint64_t* toff = ix.exon_txoff + tx.exon_begin;
   const int ne = (int)tx.n_exons;
@@ -353,7 +397,7 @@ __device__ int lift_markers(Wctx& c, const IX& ix, const thm_tx& tx, const uint8
   }
   thm_exon cur = uload(&ex[e]);
   int exon_sum = (int)uload(&toff[e]);
-  gx_ystart = (int)cur.start + (ystart - exon_sum);
+  gx_ystart = (S)cur.start + (S)(ystart - exon_sum);
   // transcript positions advance on Match / Subst / Del; total must equal yend - ystart (:154)
   int n_adv = 0;
   #pragma unroll 1
@@ -386,8 +430,9 @@ __device__ int lift_markers(Wctx& c, const IX& ix, const thm_tx& tx, const uint8
     }
     if (kstar < 0) break;                        // cannot happen when n_adv is consistent
     if (kstar >= n && !trailing_clip) break;     // boundary reached by the very last op: no further iteration
-    if (n_y >= MAX_YCLIPS) {
-      c.fault |= FAULT_INTERNAL;
+    if (n_y >= c.mk_cap) {
+      // more introns than the marker list holds: the any-width kernel (list sized by the longest transcript) takes the read
+      c.fault |= W::GS ? FAULT_INTERNAL : FAULT_RETRY;
       break;
     }
     const thm_exon nxt = uload(&ex[e + 1]);
@@ -400,8 +445,8 @@ __device__ int lift_markers(Wctx& c, const IX& ix, const thm_tx& tx, const uint8
     cur = nxt;
     e++;
   }
-  gx_yend = (int)cur.start + (yend - exon_sum);
-  wfence();
+  gx_yend = (S)cur.start + (S)(yend - exon_sum);
+  wsync(c);
   PROF_MARK(c, PS_LIFT);
   return n_y;
 }
@@ -410,8 +455,8 @@ __device__ int lift_markers(Wctx& c, const IX& ix, const thm_tx& tx, const uint8
 // global op pool, every lane writing its own bytes; `reverse` mirrors the whole
 // list (concat_to_chr_aln on a reverse-strand Ref, src/aligner.rs:440-447).
 // Returns the pool offset, byte count in n_bytes.
-template <class PP>
-__device__ unsigned long long emit_alignment(Wctx& c, const PP& p, const uint8_t* path, int n, int xstart, int xend,
+template <class W, class PP>
+__device__ unsigned long long emit_alignment(W& c, const PP& p, const uint8_t* path, int n, int xstart, int xend,
                                              bool reverse, int n_y, int& n_bytes) {
   const int lane = lane_id();
   const int lead = xstart, trail = c.L - xend;
@@ -457,52 +502,121 @@ __device__ unsigned long long emit_alignment(Wctx& c, const PP& p, const uint8_t
       o[reverse ? total - (pos + 1) : pos] = path[k];
     }
   }
-  if (lane < n_y) {
-    const int pos = lead5 + c.mk_k[lane] + 5 * lane;
-    put5(reverse ? total - (pos + 5) : pos, THM_OP_YCLIP, c.ycl[lane]);
+  #pragma unroll 1
+  for (int m = lane; m < n_y; m += 64) {
+    const int pos = lead5 + c.mk_k[m] + 5 * m;
+    put5(reverse ? total - (pos + 5) : pos, THM_OP_YCLIP, c.ycl[m]);
   }
   if (lane == 0 && lead > 0) put5(reverse ? total - 5 : 0, THM_OP_XCLIP, (uint32_t)lead);
   if (lane == 1 && trail > 0) put5(reverse ? 0 : total - 5, THM_OP_XCLIP, (uint32_t)trail);
   return off;
 }
 
+// per-wave buffer sizes, shared by the kernel's carve-up and the host's sizing functions
+struct ExtCaps {
+  uint32_t lcap, wcap, ycols, trb, opcap;
+};
+__host__ __device__ inline ExtCaps ext_caps(uint32_t max_read_len, uint32_t max_bw) {
+  ExtCaps k;
+  k.lcap = (max_read_len + 31u) & ~15u;
+  k.wcap = (2u * (max_read_len + max_bw) + max_read_len + 48u) & ~15u;
+  k.ycols = max_read_len + max_bw + 2u;
+  k.trb = (k.ycols + 1u) * 16u;  // LDS trace: one cell per lane; wider extensions use trace_g
+  k.opcap = (2u * max_read_len + 2u * max_bw + 31u) & ~15u;
+  return k;
+}
+// any-width kernel: layout of one wave's slice of global memory
+struct SlowLayout {
+  uint64_t rd, win, wing, pa, pb, pc, mk_k, ycl, dp, trace, total;
+  uint32_t dp_stride;
+};
+__host__ __device__ inline SlowLayout slow_layout(uint32_t max_read_len, uint32_t max_bw, uint32_t mk_cap) {
+  const ExtCaps k = ext_caps(max_read_len, max_bw);
+  SlowLayout s;
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) {
+    const uint64_t at = o;
+    o += (bytes + 63u) & ~63ull;
+    return at;
+  };
+  s.rd = take(k.lcap);
+  s.win = take(k.wcap);
+  s.wing = take(k.wcap);
+  s.pa = take(k.opcap);
+  s.pb = take(k.opcap);
+  s.pc = take(k.opcap);
+  s.mk_k = take((uint64_t)mk_cap * 4);
+  s.ycl = take((uint64_t)mk_cap * 4);
+  const uint32_t tiles = (2u * max_bw + 1u + 63u) / 64u;
+  s.dp_stride = tiles * 64u + 64u;
+  s.dp = take((uint64_t)s.dp_stride * 4u * 4u);
+  s.trace = take((uint64_t)(k.ycols + 1u) * tiles * 16u);
+  s.total = o;
+  return s;
+}
+
 #ifndef THM_KARG_QUAL
 #define THM_KARG_QUAL volatile
 #endif
-template <int CPL, int MINW>
-__global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_value) {
-  // The parameter block (about 70 dwords) is read from the kernel-argument segment where it is
+// C: coordinate width.  CPL: band slots per lane of the register-resident DP (1..4), or 0 for the any-width
+// kernel (band in tiles, wave-private buffers in global memory): the slow path for reads whose band or length
+// exceeds what LDS and registers hold.  MINW: waves per SIMD the register budget is set for.
+template <class C, int CPL, int MINW>
+__global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by_value) {
+  typedef typename CoordTraits<C>::S S;
+  constexpr bool GS = (CPL == 0);
+  typedef WctxT<GS> Wctx;
+  // The parameter block (about 80 dwords) is read from the kernel-argument segment where it is
   // needed (scalar loads, THM_KARG_QUAL = volatile keeps them at their use sites) instead of being
   // loaded at entry: the kernel is far over the scalar register budget, and every parameter that
   // lives in a register across the hit loop is spilled to VGPR lanes and read back with v_readlane.
 #if __HIP_DEVICE_COMPILE__
-  typedef THM_KARG_QUAL const __attribute__((address_space(4))) ExtendParams KArgs;
+  typedef THM_KARG_QUAL const __attribute__((address_space(4))) ExtendParamsT<C> KArgs;
   KArgs& p = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
 #else
-  const ExtendParams& p = p_by_value;
+  const ExtendParamsT<C>& p = p_by_value;
 #endif
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
-  // ---- LDS carve (must match extend_lds_bytes) ----
-  const uint32_t lcap = (p.max_read_len + 31u) & ~15u;
-  const uint32_t wcap = (2u * (p.max_read_len + p.max_bw) + p.max_read_len + 48u) & ~15u;
-  const uint32_t ycols = p.max_read_len + p.max_bw + 2u;
-  const uint32_t trb = (ycols + 1u) * 16u;  // LDS trace: one cell per lane; wider extensions use trace_g
-  const uint32_t opcap = (2u * p.max_read_len + 2u * p.max_bw + 31u) & ~15u;
-  const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * MAX_YCLIPS;
-  uint8_t* base = smem + (size_t)wave * per_wave;
+  const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
+  // ---- wave-private buffers (LDS carve must match extend_lds_bytes; global layout = slow_layout) ----
+  const ExtCaps caps = ext_caps(p.max_read_len, p.max_bw);
+  const uint32_t lcap = caps.lcap, wcap = caps.wcap, opcap = caps.opcap;
   Wctx c;
-  c.rd = base;
-  c.win = c.rd + lcap;
-  c.wing = c.win + wcap;
-  c.trace = (unsigned long long*)(c.wing + wcap);
-  c.trace_g = p.trace_scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) * ((size_t)(ycols + 1u) * CPL * 2u);
-  c.pa = (uint8_t*)c.trace + trb;
-  c.pb = c.pa + opcap;
-  c.pc = c.pb + opcap;
-  c.mk_k = (int*)(c.pc + opcap);
-  c.ycl = (uint32_t*)(c.mk_k + MAX_YCLIPS);
+  if constexpr (GS) {
+    const SlowLayout sl = slow_layout(p.max_read_len, p.max_bw, p.mk_cap);
+    uint8_t* base = p.slow_scratch + (size_t)wave_global * p.slow_scratch_per_wave;
+    c.rd = base + sl.rd;
+    c.win = base + sl.win;
+    c.wing = base + sl.wing;
+    c.trace = nullptr;
+    c.trace_g = (unsigned long long*)(base + sl.trace);
+    c.pa = base + sl.pa;
+    c.pb = base + sl.pb;
+    c.pc = base + sl.pc;
+    c.mk_k = (int*)(base + sl.mk_k);
+    c.ycl = (uint32_t*)(base + sl.ycl);
+    c.dp = (int*)(base + sl.dp);
+    c.dp_stride = (int)sl.dp_stride;
+    c.mk_cap = (int)p.mk_cap;
+  } else {
+    const uint32_t per_wave = lcap + 2u * wcap + caps.trb + 3u * opcap + 8u * FAST_MAX_YCLIPS;
+    uint8_t* base = smem + (size_t)wave * per_wave;
+    c.rd = base;
+    c.win = c.rd + lcap;
+    c.wing = c.win + wcap;
+    c.trace = (unsigned long long*)(c.wing + wcap);
+    c.trace_g = p.trace_scratch + (size_t)wave_global * ((size_t)(caps.ycols + 1u) * (CPL > 0 ? CPL : 1) * 2u);
+    c.pa = (uint8_t*)c.trace + caps.trb;
+    c.pb = c.pa + opcap;
+    c.pc = c.pb + opcap;
+    c.mk_k = (int*)(c.pc + opcap);
+    c.ycl = (uint32_t*)(c.mk_k + FAST_MAX_YCLIPS);
+    c.dp = nullptr;
+    c.dp_stride = 0;
+    c.mk_cap = FAST_MAX_YCLIPS;
+  }
   c.opcap = (int)opcap;
   c.wcap = (int)wcap;
   c.cells = c.cols = c.calls = c.winbytes = 0;
@@ -522,6 +636,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
   unsigned long long k_aligned = 0, k_unmapped = 0, k_alns = 0, k_reads = 0, k_opb = 0;
   unsigned k_type[3] = {0, 0, 0};  // wave-uniform (counted with ballots)
   unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
+  int batch_fault = 0;
 
   // Reads are handed out by atomic counters, QCHUNK at a time.  Small chunks balance the waves
   // (the cost per read varies by orders of magnitude: repeats), but one hot word serves only ~88 M
@@ -533,23 +648,25 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
 #endif
   constexpr unsigned QCHUNK = THM_EXT_QCHUNK;
   unsigned q_next = 0, q_end = 0;
-  const unsigned n_total = (unsigned)p.reads.n_reads;
+  const bool list_only = GS || p.list_only != 0;
+  const unsigned n_total = list_only ? 0u : (unsigned)p.reads.n_reads;
   const unsigned q_share = (n_total + EXT_NQ - 1) / EXT_NQ;
-  unsigned my_q = (blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % EXT_NQ, q_tried = 0;
+  unsigned my_q = wave_global % EXT_NQ, q_tried = 0;
   // Longest jobs first: reads with many seed hits (repeats; up to a few hundred hits, i.e.
-  // milliseconds, against ~50 us for a typical read) are listed by plan_heavy_kernel and handed
+  // milliseconds, against ~50 us for a typical read) are listed by plan_kernel and handed
   // out before everything else, one per wave; left in input order the last ones would start near
   // the end of the batch and the whole grid would wait for them (a quarter of the kernel's time
-  // on the benchmark workload).
+  // on the benchmark workload).  The any-width kernel works from its list alone.
   bool heavy_phase = true;
   const unsigned n_heavy = (unsigned)uload(p.heavy_count);
+  const unsigned list_q = (GS ? EXT_NQ + 1 : EXT_NQ) * EXT_QSTRIDE;
   for (;;) {
     bool from_heavy = false;
     if (q_next == q_end) {
       bool got = false;
       if (heavy_phase) {
         unsigned g = 0;
-        if (lane == 0) g = atomicAdd(p.queue + EXT_NQ * EXT_QSTRIDE, 1u);
+        if (lane == 0) g = atomicAdd(p.queue + list_q, 1u);
         g = (unsigned)bcast_first((int)g);
         if (g < n_heavy) {
           q_next = (unsigned)uload(&p.heavy[g]);
@@ -560,7 +677,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
           heavy_phase = false;
         }
       }
-      while (!got && q_tried < EXT_NQ) {
+      while (!got && q_tried < EXT_NQ && n_total) {
         unsigned g = 0;
         if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, QCHUNK);
         g = (unsigned)bcast_first((int)g);
@@ -578,11 +695,14 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
     }
     const unsigned idx = q_next++;
     const uint64_t r0 = uload(&p.reads.offsets[idx]);
-    const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
+    const uint64_t Lfull = uload(&p.reads.offsets[idx + 1]) - r0;
+    // not this launch's read: the slow class (and reads beyond every class) are listed by plan_kernel
+    if (Lfull > (uint64_t)p.max_read_len) continue;
+    const int L = (int)Lfull;
     c.L = L;
     #pragma unroll 1
     for (int t = lane; t < (int)lcap; t += 64) c.rd[t] = (t < L) ? p.reads.bases[r0 + t] : (uint8_t)0;  // already upper-cased and sanitised
-    wfence();
+    wsync(c);
 
     // thresholds, reference src/aligner.rs:130-138 (binary32 product, truncation toward zero)
     const float prod = p.opts.min_aln_score_percent * (float)L;
@@ -593,7 +713,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
     int x_drop = band_width;
     const int range = (int)p.opts.multimap_score_range;
     const bool intron_mode = p.opts.intron_mode != 0;
-    if (band_width > (int)p.max_bw || 2 * band_width + 1 > 64 * CPL) {
+    if (band_width > (int)p.max_bw || (CPL > 0 && 2 * band_width + 1 > 64 * CPL)) {
       c.fault |= FAULT_INTERNAL;
       band_width = x_drop = 0;
     }
@@ -602,7 +722,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
     Cand* cands = p.cands + cand0;
     uint32_t* order = p.order + 2 * cand0;  // two scratch lists of the read's hit count each
     const uint64_t n_hits_cap = uload(&p.read_cand_off[idx + 1]) - cand0;
-    if (!from_heavy && n_hits_cap >= HEAVY_HITS) continue;  // went out with the heavy reads
+    if (!GS && !from_heavy && n_hits_cap >= HEAVY_HITS) continue;  // went out with the heavy reads
     uint32_t n_acc = 0;
     unsigned acc_bytes = 0;  // op bytes and type of the most recent accepted candidate
     int acc_type = 0;
@@ -615,34 +735,34 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
       n_sm = 0;
     }
     for (uint32_t si = 0; si < n_sm; si++) {
-      const Smem sm = uload(&p.smems[s0 + si]);
+      const SmemT<C> sm = uload(&p.smems[s0 + si]);
       const int q = sm.qpos, len = sm.len;
-      uint32_t rr = sm.hi;
+      C rr = sm.hi;
       while (rr > sm.lo) {
-        const uint32_t chunk = min(64u, rr - sm.lo);
-        uint32_t my_sa = 0;
+        const uint32_t chunk = (uint32_t)min((C)64, (C)(rr - sm.lo));
+        C my_sa = 0;
         if ((uint32_t)lane < chunk) my_sa = ix.sa[rr - 1 - lane];
         for (uint32_t t = 0; t < chunk; t++) {
-          const int hr = __builtin_amdgcn_readlane((int)my_sa, bcast_first((int)t));
+          const S hr = (S)readlane_c(my_sa, bcast_first((int)t));
           // ================= align_seed_hit (src/aligner.rs:198-314) =================
           const int bw = band_width, xd = x_drop;
           // The genome window is requested before the contig lookup so that the two memory
           // latencies overlap; it is loaded unclamped (the text is padded) and clamped to the
           // contig logically below (:212-215).
-          const int gw_a = max(hr - (L + bw), 0);
-          const int gw_b = min(hr + len + L + bw, (int)ix.n);
+          const S gw_a = max(hr - (S)(L + bw), (S)0);
+          const S gw_b = min(hr + (S)(len + L + bw), (S)ix.n);
           const unsigned gw_mis = (unsigned)((uintptr_t)(ix.text + gw_a) & 15u);
-          const int gw_n = (gw_b - gw_a) + (int)gw_mis;
+          const int gw_n = (int)(gw_b - gw_a) + (int)gw_mis;
           const uint4* gw_src = (const uint4*)(ix.text + gw_a - gw_mis);
           uint4 gw_v = make_uint4(0, 0, 0, 0);
           if (gw_n <= c.wcap && lane * 16 < gw_n) gw_v = gw_src[lane];
-          const RefInfo ref = idx_to_ref(ix, (uint32_t)hr);
-          const uint32_t qs = (uint32_t)hr, qe = (uint32_t)(hr + len);  // the seed on the concatenated text
+          const RefInfoT<C> ref = idx_to_ref<C>(ix, (C)hr);
+          const C qs = (C)hr, qe = (C)(hr + len);  // the seed on the concatenated text
 
           // One loop runs the genome extension (target 0) and then one extension per
           // transcript yielded by exon_to_tx.find (:231-258), so that the extension
           // code is instantiated once.
-          Path gx, best;
+          PathT<S> gx, best;
           gx.score = gx.nops = gx.xstart = gx.xend = 0;
           gx.ystart = gx.yend = 0;
           best = gx;
@@ -652,17 +772,17 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
           uint8_t* best_buf = c.pc;
           bool genome_done = false;
           LrMemo gmemo, tmemo;
-          GridQuery eg;
+          GridQueryT<C> eg;
           for (;;) {
-            int win0, lo_abs, hi_abs, t_r;
+            S win0, lo_abs, hi_abs, t_r;
             int t_q, t_len;
             uint8_t* buf;
             uint32_t tx_idx = 0;
             if (!genome_done) {
               // genome window (:212-215)
-              const int rs = (int)ref.start;
-              const int seq_start = max((hr > L + bw) ? hr - (L + bw) : 0, rs);
-              const int seq_end = min(hr + len + L + bw, (int)ref.end - 1);
+              const S rs = (S)ref.start;
+              const S seq_start = max((hr > L + bw) ? hr - (S)(L + bw) : (S)0, rs);
+              const S seq_end = min(hr + (S)(len + L + bw), (S)ref.end - 1);
               if (gw_n > c.wcap) {
                 c.fault |= FAULT_INTERNAL;
               } else {
@@ -672,9 +792,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
                 for (int t2 = lane + 64; t2 * 16 < gw_n; t2 += 64) wdst[t2] = gw_src[t2];
               }
               c.winbytes += (unsigned)(seq_end - seq_start);
-              wfence();
+              wsync(c);
               PROF_MARK(c, PS_STAGE);
-              win0 = gw_a - (int)gw_mis;
+              win0 = gw_a - (S)gw_mis;
               lo_abs = seq_start;
               hi_abs = seq_end;
               t_r = hr;
@@ -694,7 +814,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
                 bool hit = false;
                 if (e < tx.n_exons) {
                   const thm_exon x = ix.exons[tx.exon_begin + e];
-                  const uint32_t x0 = (uint32_t)x.start, x1 = (uint32_t)x.end;
+                  const C x0 = (C)x.start, x1 = (C)x.end;
                   hit = (qs >= x0 && qs < x1) || (x0 >= qs && x0 < qe);
                 }
                 const unsigned long long m = __ballot(hit);
@@ -706,25 +826,25 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
               }
               const thm_exon x = uload(&ix.exons[tx.exon_begin + fe]);
               const int exon_sum = (int)uload(&ix.exon_txoff[tx.exon_begin + fe]);
-              const int xs = (int)x.start, xe = (int)x.end;
-              t_r = ((hr > xs) ? hr - xs : 0) + exon_sum;
-              const int start_offset = (xs > hr) ? xs - hr : 0;
-              const int t_end = min(hr + len, xe) - xs + exon_sum;
+              const S xs = (S)x.start, xe = (S)x.end;
+              int tr_ = (int)((hr > xs) ? hr - xs : (S)0) + exon_sum;
+              const int start_offset = (int)((xs > hr) ? xs - hr : (S)0);
+              const int t_end = (int)(min(hr + (S)len, xe) - xs) + exon_sum;
               t_q = q + start_offset;
-              t_len = t_end - t_r;
+              t_len = t_end - tr_;
               const int tlen = (int)tx.seq_len;
               // window of the transcript around the lifted seed
-              const int ws = (t_r > L + bw) ? t_r - (L + bw) : 0;
-              const int we = min(tlen, t_r + t_len + L + bw + 1);
-              win0 = stage_window(c, c.win, ix.tx_seq + tx.seq_off, ws, we);
+              const int ws = (tr_ > L + bw) ? tr_ - (L + bw) : 0;
+              const int we = min(tlen, tr_ + t_len + L + bw + 1);
+              const int w0 = stage_window(c, c.win, ix.tx_seq + tx.seq_off, ws, we);
               // extend_seed_match (src/aligner.rs:410-426): ballots of the first mismatch
               {
                 int ext = 0;
                 for (bool done = false; !done;) {
                   const int tt = ext + lane;
-                  const int rp = t_r + t_len + tt;
+                  const int rp = tr_ + t_len + tt;
                   const int qp = t_q + t_len + tt;
-                  const bool ok = (rp < tlen) && (qp < L) && (c.win[rp - win0] == c.rd[qp]);
+                  const bool ok = (rp < tlen) && (qp < L) && (c.win[rp - w0] == c.rd[qp]);
                   const unsigned long long bad = __ballot(!ok);
                   if (bad) {
                     ext += __builtin_ctzll(bad);
@@ -737,9 +857,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
                 ext = 0;
                 for (bool done = false; !done;) {
                   const int tt = ext + lane + 1;
-                  const int rp = t_r - tt;
+                  const int rp = tr_ - tt;
                   const int qp = t_q - tt;
-                  const bool ok = (rp >= 0) && (qp >= 0) && (c.win[rp - win0] == c.rd[qp]);
+                  const bool ok = (rp >= 0) && (qp >= 0) && (c.win[rp - w0] == c.rd[qp]);
                   const unsigned long long bad = __ballot(!ok);
                   if (bad) {
                     ext += __builtin_ctzll(bad);
@@ -748,16 +868,18 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
                     ext += 64;
                   }
                 }
-                t_r -= ext;
+                tr_ -= ext;
                 t_q -= ext;
                 t_len += ext;
               }
+              win0 = (S)w0;
+              t_r = (S)tr_;
               lo_abs = 0;
-              hi_abs = tlen;
+              hi_abs = (S)tlen;
               buf = cur_buf;
               PROF_MARK(c, PS_TXPREP);
             }
-            Path pth;
+            PathT<S> pth;
             bool reused = false;
             if (genome_done && t_q == q && t_len == len) {
               // Same seed on the read: if the transcript window agrees with the genome
@@ -765,23 +887,23 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
               // inside one exon and the alignment does not reach its ends), the two
               // SwgExtend::extend calls would return what they returned for the genome.
               const int xr = L - (t_q + t_len);
-              const int yr = min(hi_abs - (t_r + t_len), xr + bw + 1);
-              const int rel = t_r - lo_abs;
-              const int y0 = lo_abs + (rel > L + bw ? rel - (L + bw) : 0);
-              const int yl = min(t_r - y0, t_q + bw + 1);
+              const int yr = (int)min(hi_abs - (t_r + t_len), (S)(xr + bw + 1));
+              const S rel = t_r - lo_abs;
+              const S y0 = lo_abs + (rel > L + bw ? rel - (L + bw) : (S)0);
+              const int yl = (int)min(t_r - y0, (S)(t_q + bw + 1));
               const SwgResult& R = gmemo.R;
               const SwgResult& Lt = gmemo.Lt;
               bool ok = (R.broke ? yr >= R.jmax : yr == gmemo.yr) && (Lt.broke ? yl >= Lt.jmax : yl == gmemo.yl);
               if (ok) {
-                const uint8_t* tr_ = c.win + (t_r + t_len - win0);
+                const uint8_t* tr2 = c.win + (int)(t_r + t_len - win0);
                 const uint8_t* gr_ = c.wing + gmemo.yoff_r;
-                const uint8_t* tl_ = c.win + (t_r - 1 - win0);
+                const uint8_t* tl_ = c.win + (int)(t_r - 1 - win0);
                 const uint8_t* gl_ = c.wing + gmemo.yoff_l;
                 bool differ = false;
 #pragma unroll 1
                 for (int j0 = 0; j0 < R.jmax; j0 += 64) {
                   const int j = j0 + lane;
-                  differ = differ || (j < R.jmax && tr_[j] != gr_[j]);
+                  differ = differ || (j < R.jmax && tr2[j] != gr_[j]);
                 }
 #pragma unroll 1
                 for (int j0 = 0; j0 < Lt.jmax; j0 += 64) {
@@ -800,18 +922,18 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
                 pth.yend = t_r + t_len + R.yend;
 #pragma unroll 1
                 for (int t2 = lane; t2 < gx.nops; t2 += 64) buf[t2] = c.pa[t2];
-                wfence();
+                wsync(c);
                 c.calls += 2;  // two extend() calls in the reference's terms
                 PROF_MARK(c, PS_TXPREP);
               }
             }
             if (!reused)
-              pth = extend_lr<CPL>(c, genome_done ? c.win : c.wing, win0, lo_abs, hi_abs, t_r, t_q, t_len, bw, xd, buf,
-                                   genome_done ? tmemo : gmemo);
+              pth = extend_lr<CPL, S>(c, genome_done ? c.win : c.wing, win0, lo_abs, hi_abs, t_r, t_q, t_len, bw, xd, buf,
+                                      genome_done ? tmemo : gmemo);
             if (!genome_done) {
               gx = pth;
               genome_done = true;
-              grid_begin(eg, ix.exon_grid_off, ix.exon_grid, qs, qe);
+              grid_begin<C>(eg, ix.exon_grid_off, ix.exon_grid, qs, qe);
             } else {
               if (!have_best || pth.score > best.score) {  // strictly better (:249)
                 have_best = true;
@@ -828,7 +950,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
           // ---- exonic vs unspliced (:263-313) ----
           int aln_type;
           uint32_t type_idx = THM_NO_IDX;
-          int cy0, cy1;  // concatenated coordinates of the genome alignment
+          S cy0, cy1;  // concatenated coordinates of the genome alignment
           const uint8_t* g_path;
           int g_n, g_ny = 0;
           int sc, xs_, xe_;
@@ -857,11 +979,12 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
           if (sc < p.opts.min_aln_score || sc < min_aln_score || sc < max_aln_score - range) accept = false;
           if (accept) {
             if (exonic) {
-              g_ny = lift_markers(c, ix, uload(&ix.txs[best_tx]), best_buf, best.nops, best.xend < L, best.ystart, best.yend, cy0, cy1);
+              g_ny = lift_markers<S>(c, ix, uload(&ix.txs[best_tx]), best_buf, best.nops, best.xend < L, (int)best.ystart,
+                                     (int)best.yend, cy0, cy1);
             } else {
               // first interval gene_intervals.find yields (:283-288, :306); only reached in intron mode
-              GridQuery gg;
-              grid_begin(gg, ix.gene_grid_off, ix.gene_grid, (uint32_t)cy0, (uint32_t)cy1);
+              GridQueryT<C> gg;
+              grid_begin<C>(gg, ix.gene_grid_off, ix.gene_grid, (C)cy0, (C)cy1);
               uint32_t gene = 0;
               if (grid_next(gg, gene)) {
                 aln_type = THM_ALN_INTRONIC;
@@ -870,16 +993,16 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
               PROF_MARK(c, PS_TREE);
             }
             // concat_to_chr_aln (:429-449)
-            const RefInfo cref = idx_to_ref(ix, (uint32_t)cy0);
-            uint32_t ch0, ch1;
+            const RefInfoT<C> cref = idx_to_ref<C>(ix, (C)cy0);
+            uint64_t ch0, ch1;
             bool rev;
             if (cref.strand) {
-              ch0 = (uint32_t)cy0 - cref.start;
-              ch1 = (uint32_t)cy1 - cref.start;
+              ch0 = (uint64_t)((C)cy0 - cref.start);
+              ch1 = (uint64_t)((C)cy1 - cref.start);
               rev = false;
             } else {
-              ch0 = cref.len - ((uint32_t)cy1 - cref.start);
-              ch1 = cref.len - ((uint32_t)cy0 - cref.start);
+              ch0 = (uint64_t)(C)(cref.len - ((C)cy1 - cref.start));
+              ch1 = (uint64_t)(C)(cref.len - ((C)cy0 - cref.start));
               rev = true;
             }
             int nb = 0, tnb = 0;
@@ -937,6 +1060,27 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
       }
     }
     PROF_MARK(c, PS_OTHER);
+    // per-read outcomes that are not alignments
+    if (c.fault & FAULT_RETRY) {
+      // more introns in one alignment than this kernel's marker list holds: the any-width kernel redoes the read
+      c.fault &= ~(FAULT_RETRY | FAULT_CONTRACT);
+      if (lane == 0) {
+        const unsigned long long slot = atomicAdd(p.retry_count, 1ull);
+        p.retry[slot] = idx;
+      }
+      c.cells = c.cols = c.calls = c.winbytes = 0;
+      continue;
+    }
+    if (c.fault & FAULT_CONTRACT) {
+      // a condition that panics in the reference (lift_mem_to_tx / lift_tx_to_gx): no alignments, per-read status
+      c.fault &= ~FAULT_CONTRACT;
+      n_acc = 0;
+      if (lane == 0) {
+        p.read_status[idx] = THM_ERR_OUT_OF_CONTRACT;
+        atomicAdd(p.n_contract, 1ull);
+      }
+    }
+    batch_fault |= c.fault;
     uint32_t nres = 0;
     unsigned long long opb = 0;
     if (n_acc == 1) {
@@ -1068,7 +1212,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
     k_calls += c.calls;
     k_win += c.winbytes;
     c.cells = c.cols = c.calls = c.winbytes = 0;
-    wfence();
+    wsync(c);
   }
 #ifdef THM_PROF
   if (lane == 0 && p.prof)
@@ -1077,8 +1221,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParams p_by_val
       for (int t = 0; t < 3; t++) atomicAdd(&p.prof[10 + t], c.prof_cols[t]);
     }
 #endif
+  batch_fault |= c.fault & (FAULT_OPS_POOL | FAULT_INTERNAL);
   if (lane == 0) {
-    if (c.fault) atomicOr(p.fault, c.fault);
+    if (batch_fault) atomicOr(p.fault, batch_fault & (FAULT_OPS_POOL | FAULT_INTERNAL));
     if (k_reads) {
       atomicAdd(&p.counters[THM_CNT_READS], k_reads);
       atomicAdd(&p.counters[THM_CNT_ALIGNED], k_aligned);
@@ -1158,12 +1303,8 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
 }  // namespace dev
 
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
-  const uint32_t lcap = (max_read_len + 31u) & ~15u;
-  const uint32_t wcap = (2u * (max_read_len + max_bw) + max_read_len + 48u) & ~15u;
-  const uint32_t ycols = max_read_len + max_bw + 2u;
-  const uint32_t trb = (ycols + 1u) * 16u;
-  const uint32_t opcap = (2u * max_read_len + 2u * max_bw + 31u) & ~15u;
-  const uint32_t per_wave = lcap + 2u * wcap + trb + 3u * opcap + 8u * dev::MAX_YCLIPS;
+  const dev::ExtCaps k = dev::ext_caps(max_read_len, max_bw);
+  const uint32_t per_wave = k.lcap + 2u * k.wcap + k.trb + 3u * k.opcap + 8u * FAST_MAX_YCLIPS;
   (void)cpl;
   return 4 * (size_t)per_wave;
 }
@@ -1173,8 +1314,14 @@ size_t extend_trace_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, int cp
   return cpl > 1 ? (size_t)(max_read_len + max_bw + 3u) * (size_t)cpl * 16u : 0;
 }
 
-hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream_t s) {
-  const size_t lds = extend_lds_bytes(p.max_read_len, p.max_bw, cpl);
+// everything one wave of the any-width kernel keeps in global memory, in bytes
+size_t extend_slow_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, uint32_t mk_cap) {
+  return (size_t)dev::slow_layout(max_read_len, max_bw, mk_cap).total;
+}
+
+template <class C>
+static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_blocks, hipStream_t s) {
+  const size_t lds = cpl == 0 ? 0 : extend_lds_bytes(p.max_read_len, p.max_bw, cpl);
   auto go = [&](auto kern) -> hipError_t {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1183,36 +1330,46 @@ hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
-  // register budget: MINW waves per SIMD.  Defaults, measured: 8 for the one-cell-per-lane kernel (64
-  // VGPRs plus spilled ones), 6 for the two-cell-per-lane kernel (80 VGPRs plus spilled ones; with
-  // the wide-band trace in global memory its LDS footprint admits 8 workgroups per CU for 91 bp
-  // reads), 4 for wider bands.  The spilled registers cost scratch traffic (about 0.6 GB per 500 k-read
-  // launch, against a kernel that uses 2 % of the HBM bandwidth) and buy 8 % more throughput than 5
-  // waves; tuning knob THM_EXT_MINW = 2..6 | 8.
+  // register budget: MINW waves per SIMD.  Measured on the 32-bit-coordinate kernels: 8 for the one-cell-per-lane
+  // kernel (64 VGPRs plus spilled ones), 6 for the two-cell-per-lane kernel (80 VGPRs plus spilled ones; with the
+  // wide-band trace in global memory its LDS footprint admits 8 workgroups per CU for 91 bp reads), 4 for wider
+  // bands.  The spilled registers cost scratch traffic and buy 8 % more throughput than 5 waves; tuning knob
+  // THM_EXT_MINW = 4 | 5 | 6 | 8 for the one- and two-cell kernels.  The 64-bit-coordinate kernels carry
+  // more live state per hit and run at 4 waves per SIMD.
   static const int minw_env = [] {
     const char* e = getenv("THM_EXT_MINW");
     const int v = e ? atoi(e) : 0;
-    return (v >= 2 && v <= 8) ? v : 0;
+    return (v >= 4 && v <= 8) ? v : 0;
   }();
-  const int minw = minw_env ? minw_env : (cpl == 1 ? 8 : (cpl == 2 ? 6 : 4));
-#define THM_EXT_CASE(C)                                  \
-  case C:                                                \
-    if (minw == 4) return go(dev::extend_kernel<C, 4>);  \
-    if (minw == 3) return go(dev::extend_kernel<C, 3>);  \
-    if (minw == 2) return go(dev::extend_kernel<C, 2>);  \
-    if (C <= 2 && minw == 5) return go(dev::extend_kernel<(C <= 2 ? C : 1), 5>);  \
-    if (C <= 2 && minw == 6) return go(dev::extend_kernel<(C <= 2 ? C : 1), 6>);  \
-    if (C <= 2 && minw == 8) return go(dev::extend_kernel<(C <= 2 ? C : 1), 8>);  \
-    return go(dev::extend_kernel<C, 4>);
-  switch (cpl) {
-    THM_EXT_CASE(1)
-    THM_EXT_CASE(2)
-    THM_EXT_CASE(3)
-    THM_EXT_CASE(4)
-    default: return hipErrorInvalidValue;
+  if (cpl == 0) return go(dev::extend_kernel<C, 0, 2>);
+  if constexpr (sizeof(C) == 8) {
+    switch (cpl) {
+      case 1: return go(dev::extend_kernel<C, 1, 4>);
+      case 2: return go(dev::extend_kernel<C, 2, 4>);
+      case 3: return go(dev::extend_kernel<C, 3, 4>);
+      case 4: return go(dev::extend_kernel<C, 4, 4>);
+      default: return hipErrorInvalidValue;
+    }
+  } else {
+    const int minw = minw_env ? minw_env : (cpl == 1 ? 8 : (cpl == 2 ? 6 : 4));
+    switch (cpl) {
+      case 1:
+        if (minw == 4) return go(dev::extend_kernel<C, 1, 4>);
+        if (minw == 6) return go(dev::extend_kernel<C, 1, 6>);
+        return go(dev::extend_kernel<C, 1, 8>);
+      case 2:
+        if (minw == 4) return go(dev::extend_kernel<C, 2, 4>);
+        if (minw == 5) return go(dev::extend_kernel<C, 2, 5>);
+        if (minw == 8) return go(dev::extend_kernel<C, 2, 8>);
+        return go(dev::extend_kernel<C, 2, 6>);
+      case 3: return go(dev::extend_kernel<C, 3, 4>);
+      case 4: return go(dev::extend_kernel<C, 4, 4>);
+      default: return hipErrorInvalidValue;
+    }
   }
-#undef THM_EXT_CASE
 }
+hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s) { return launch_extend_t(p, cpl, n_blocks, s); }
+hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s) { return launch_extend_t(p, cpl, n_blocks, s); }
 
 hipError_t launch_compact(const CompactParams& p, hipStream_t s) {
   const unsigned blocks = (unsigned)((p.n_reads + 15) / 16);

@@ -108,9 +108,9 @@ __device__ __forceinline__ int lcp_cmp(const uint8_t* tp, const uint8_t* q, int 
 //   4. larger intervals (repeats): lower bound of the whole query tail by binary
 //      search, the better of the two neighbours of the insertion point gives the
 //      match length, two more binary searches give the interval.
-__device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int pos, int k, int& out_d, uint32_t& out_lo,
-                          uint32_t& out_hi) {
-  uint32_t lo = 0, hi = (uint32_t)ix.n;
+template <class C>
+__device__ void ms_search(const DeviceIndexT<C>& ix, const uint8_t* rd, int L, int pos, int k, int& out_d, C& out_lo, C& out_hi) {
+  C lo = 0, hi = (C)ix.n;
   int d = 0;
   const int kt = (int)ix.kt;
   if (kt <= k) {
@@ -123,7 +123,7 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
       code = (code << 2) | (uint32_t)(c & 3);
     }
     if (acgt) {
-      const LutEntry e = ix.lut[code];
+      const LutEntryT<C> e = ix.lut[code];
       lo = e.lo;
       hi = e.hi;
       d = kt;
@@ -133,16 +133,16 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
     const int cap = L - (pos + d);
     const uint8_t* q = rd + pos + d;
     bool less;
-    const uint32_t sz = hi - lo;
+    const C sz = hi - lo;
     if (sz == 1) {
       d += lcp_cmp<false>(ix.text + ix.sa[lo] + d, q, cap, &less);
     } else if (q[0] != 0) {  // a byte outside ACGTN matches nothing: the interval stays at depth d
       if (sz <= 8) {
-        uint32_t sav[8];
+        C sav[8];
         uint64_t tw[8];
         int lc[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) sav[u] = (lo + u < hi) ? ix.sa[lo + u] : 0u;
+        for (int u = 0; u < 8; u++) sav[u] = (lo + u < hi) ? ix.sa[lo + u] : (C)0;
 #pragma unroll
         for (int u = 0; u < 8; u++) tw[u] = load8_global(ix.text + sav[u] + d);
         const uint64_t qw = load8_global(q);
@@ -161,12 +161,12 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
           ms = max(ms, lc[u]);
         }
         if (ms > 0) {
-          uint32_t nlo = hi, nhi = lo;
+          C nlo = hi, nhi = lo;
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             if (lc[u] == ms) {
-              nlo = min(nlo, lo + u);
-              nhi = max(nhi, lo + u + 1);
+              nlo = min(nlo, (C)(lo + u));
+              nhi = max(nhi, (C)(lo + u + 1));
             }
           }
           lo = nlo;
@@ -174,9 +174,9 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
           d += ms;
         }
       } else {
-        uint32_t a = lo, b = hi;
+        C a = lo, b = hi;
         while (a < b) {
-          const uint32_t m = a + ((b - a) >> 1);
+          const C m = a + ((b - a) >> 1);
           (void)lcp_cmp<true>(ix.text + ix.sa[m] + d, q, cap, &less);
           if (less)
             a = m + 1;
@@ -188,11 +188,11 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
         if (a < hi) l2 = lcp_cmp<true>(ix.text + ix.sa[a] + d, q, cap, &less);
         const int ms = max(l1, l2);
         if (ms > 0) {
-          uint32_t nlo = a, nhi = a;
+          C nlo = a, nhi = a;
           if (l1 >= ms) {  // leftmost suffix in [lo, a) that still shares ms characters
-            uint32_t x = lo, y = a - 1;
+            C x = lo, y = a - 1;
             while (x < y) {
-              const uint32_t m = x + ((y - x) >> 1);
+              const C m = x + ((y - x) >> 1);
               if (lcp_cmp<true>(ix.text + ix.sa[m] + d, q, ms, &less) >= ms)
                 y = m;
               else
@@ -201,9 +201,9 @@ __device__ void ms_search(const DeviceIndex& ix, const uint8_t* rd, int L, int p
             nlo = x;
           }
           if (l2 >= ms) {  // one past the rightmost suffix in [a, hi) that shares ms characters
-            uint32_t x = a + 1, y = hi;
+            C x = a + 1, y = hi;
             while (x < y) {
-              const uint32_t m = x + ((y - x) >> 1);
+              const C m = x + ((y - x) >> 1);
               if (lcp_cmp<true>(ix.text + ix.sa[m] + d, q, ms, &less) >= ms)
                 x = m + 1;
               else
@@ -252,30 +252,21 @@ __global__ void sanitize_kernel(const uint8_t* in, uint8_t* out, uint64_t n, uin
 //   seed_first_kernel  position 0 of every read.  If that match spans the read (the common
 //                      case for error-free reads) it is the read's only SMEM: it is emitted
 //                      here and the read leaves the seed stage after one probe.  The other
-//                      reads go on a work list.
+//                      reads go on a work list (one for reads of at most SHORT_READ_MAX bases,
+//                      one for longer reads: a few long reads in a batch of short ones must not
+//                      size the launches of the short ones).
 //   seed_grid_kernel   every PROBE_STRIDE-th position and the last one, for listed reads.
 //   seed_cells_kernel  one thread per grid cell (the positions between two grid points): when
 //                      both ends of the cell have MS >= k and the same end, every position
 //                      inside has that end too (and MS >= k), so nothing starts there and
 //                      the end is recorded without probing; other cells go on a work list.
 //   seed_fill_kernel   the inner positions of listed cells: the cells around a jump of E.
-// The work lists keep the probing launches dense (whole waves of real probes).
+// The work lists keep the probing launches dense (whole waves of real probes).  The per-position
+// arrays are ragged: the row of read r starts at slot ms_row(offsets[r], r) (launch.h).
 constexpr int PROBE_STRIDE = 8;
 
-// append `value` to a list for every lane with `flag`: one atomic per wave
-__device__ __forceinline__ void wave_append(bool flag, unsigned long long value, unsigned long long* list,
-                                            unsigned long long* count) {
-  const unsigned long long m = __ballot(flag);
-  if (m == 0ull) return;
-  const int lane = lane_id();
-  const int leader = (int)__builtin_ctzll(m);
-  unsigned long long base = 0;
-  if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(m));
-  base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)(base & 0xffffffffu), leader);
-  if (flag) list[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = value;
-}
-
-// the same for a whole 256-thread workgroup: one atomic per workgroup (every thread must call it)
+// append `value` to a list for every thread with `flag`: one atomic per 256-thread workgroup
+// (every thread must call it; the trailing barrier makes back-to-back calls safe)
 __device__ __forceinline__ void block_append(bool flag, unsigned long long value, unsigned long long* list,
                                              unsigned long long* count) {
   __shared__ unsigned w_cnt[4];
@@ -292,36 +283,43 @@ __device__ __forceinline__ void block_append(bool flag, unsigned long long value
   unsigned before = 0;
   for (int w = 0; w < wv; w++) before += w_cnt[w];
   if (flag) list[b_base + before + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = value;
+  __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void seed_first_kernel(SeedParams p) {
+template <class C>
+__global__ __launch_bounds__(256) void seed_first_kernel(SeedParamsT<C> p) {
   const uint64_t read = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = lane_id();
   const bool active = read < p.reads.n_reads;
-  const uint32_t P = p.pos_per_read;
   const int k = (int)p.min_seed_len;
   int d = 0, L = 0;
-  uint32_t lo = 0, hi = 0;
+  C lo = 0, hi = 0;
+  bool too_long = false;
   if (active) {
     const uint64_t r0 = p.reads.offsets[read];
-    L = (int)(p.reads.offsets[read + 1] - r0);
+    const uint64_t Lfull = p.reads.offsets[read + 1] - r0;
+    too_long = Lfull > MAX_READ_LEN;
+    L = too_long ? 0 : (int)Lfull;
+    if (too_long) p.read_status[read] = THM_ERR_UNSUPPORTED;
     if (k <= L) ms_search(p.ix, p.reads.bases + r0, L, 0, k, d, lo, hi);
-    const uint64_t item = read * P;
-    p.ms_end[item] = (uint16_t)((d >= k) ? d : 0);
-    p.ms_lo[item] = lo;
-    p.ms_hi[item] = hi;
+    if (L > 0) {
+      const uint64_t item = ms_row(r0, read);
+      p.ms_end[item] = (uint16_t)((d >= k) ? d : 0);
+      p.ms_lo[item] = lo;
+      p.ms_hi[item] = hi;
+    }
   }
   const bool covered = active && d >= k && d == L;
-  // reads with more positions to look at
-  // reads that are not finished here: more positions to probe, or (a single position) left to seed_select_kernel
+  // reads that are not finished here: more positions to probe, or (a single position) left to the selection kernels
   const bool more = active && !covered && L - k + 1 >= 1;
-  block_append(more, read, p.work_reads, &p.work_counts[0]);
-  if (active && !covered && !more) {  // shorter than a seed: no SMEMs
+  block_append(more && L <= (int)SHORT_READ_MAX, read, p.work_short, &p.work_counts[0]);
+  block_append(more && L > (int)SHORT_READ_MAX, read, p.work_long, &p.work_counts[4]);
+  if (active && !covered && !more) {  // shorter than a seed (or beyond MAX_READ_LEN): no SMEMs
     p.read_smem_off[read] = 0;
     p.read_smem_cnt[read] = 0;
     p.read_hits[read] = 0;
   }
-  // a covered read is done: its one SMEM goes to the pool here (seed_select_kernel skips it)
+  // a covered read is done: its one SMEM goes to the pool here (the selection kernels never see it)
   const unsigned long long m = __ballot(covered);
   if (m) {
     const int leader = (int)__builtin_ctzll(m);
@@ -333,7 +331,7 @@ __global__ __launch_bounds__(256) void seed_first_kernel(SeedParams p) {
     if (covered) {
       const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
       if (fits) {
-        Smem sm;
+        SmemT<C> sm;
         sm.lo = lo;
         sm.hi = hi;
         sm.qpos = 0;
@@ -354,13 +352,14 @@ __global__ __launch_bounds__(256) void seed_first_kernel(SeedParams p) {
   }
 }
 
-__global__ __launch_bounds__(256) void seed_grid_kernel(SeedParams p) {
+// `list[0 .. *count)`: the reads of one length class; G = grid slots per read for the longest read of the class
+template <class C>
+__global__ __launch_bounds__(256) void seed_grid_kernel(SeedParamsT<C> p, const unsigned long long* list,
+                                                        const unsigned long long* count, uint32_t G) {
   const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t P = p.pos_per_read;
-  const uint32_t G = (P + PROBE_STRIDE - 1) / PROBE_STRIDE + 1;  // slots per read: the grid and the last position
   const uint64_t wi = tid / G;
-  if (wi >= p.work_counts[0]) return;
-  const uint64_t read = p.work_reads[wi];
+  if (wi >= *count) return;
+  const uint64_t read = list[wi];
   const int g = (int)(tid - wi * G);
   const uint64_t r0 = p.reads.offsets[read];
   const int L = (int)(p.reads.offsets[read + 1] - r0);
@@ -370,31 +369,31 @@ __global__ __launch_bounds__(256) void seed_grid_kernel(SeedParams p) {
   // position 0 was probed by seed_first_kernel; the last position is probed once (by the extra slot)
   if (pos <= 0 || pos >= npos || (g + 1 != (int)G && pos == npos - 1)) return;
   int d = 0;
-  uint32_t lo = 0, hi = 0;
+  C lo = 0, hi = 0;
   ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
-  const uint64_t item = read * P + (uint64_t)pos;
+  const uint64_t item = ms_row(r0, read) + (uint64_t)pos;
   p.ms_end[item] = (uint16_t)((d >= k) ? pos + d : 0);
   p.ms_lo[item] = lo;
   p.ms_hi[item] = hi;
 }
 
-__global__ __launch_bounds__(256) void seed_cells_kernel(SeedParams p) {
+template <class C>
+__global__ __launch_bounds__(256) void seed_cells_kernel(SeedParamsT<C> p, const unsigned long long* list,
+                                                         const unsigned long long* count, uint32_t NC) {
   const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t P = p.pos_per_read;
-  const uint32_t C = (P + PROBE_STRIDE - 1) / PROBE_STRIDE;  // cells per read
-  const uint64_t wi = tid / C;
+  const uint64_t wi = tid / NC;
   bool todo = false;
   uint64_t read = 0;
   int c = 0;
-  if (wi < p.work_counts[0]) {
-    read = p.work_reads[wi];
-    c = (int)(tid - wi * C);
+  if (wi < *count) {
+    read = list[wi];
+    c = (int)(tid - wi * NC);
     const uint64_t r0 = p.reads.offsets[read];
     const int L = (int)(p.reads.offsets[read + 1] - r0);
     const int npos = L - (int)p.min_seed_len + 1;
     const int a = c * PROBE_STRIDE, b = min(a + PROBE_STRIDE, npos - 1);
     if (b - a > 1) {  // the cell has inner positions
-      const uint64_t item0 = read * P;
+      const uint64_t item0 = ms_row(r0, read);
       const int ea = p.ms_end[item0 + (uint64_t)a], eb = p.ms_end[item0 + (uint64_t)b];
       if (ea != 0 && ea == eb) {
         for (int q = a + 1; q < b; q++) p.ms_end[item0 + (uint64_t)q] = (uint16_t)ea;  // same end: nothing starts here
@@ -406,7 +405,8 @@ __global__ __launch_bounds__(256) void seed_cells_kernel(SeedParams p) {
   block_append(todo, (read << 16) | (unsigned long long)c, p.work_cells, &p.work_counts[1]);
 }
 
-__global__ __launch_bounds__(256) void seed_fill_kernel(SeedParams p) {
+template <class C>
+__global__ __launch_bounds__(256) void seed_fill_kernel(SeedParamsT<C> p) {
   const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t ci = tid / PROBE_STRIDE;
   if (ci >= p.work_counts[1]) return;
@@ -415,7 +415,6 @@ __global__ __launch_bounds__(256) void seed_fill_kernel(SeedParams p) {
   const unsigned long long w = p.work_cells[ci];
   const uint64_t read = w >> 16;
   const int c = (int)(w & 0xffffu);
-  const uint32_t P = p.pos_per_read;
   const uint64_t r0 = p.reads.offsets[read];
   const int L = (int)(p.reads.offsets[read + 1] - r0);
   const int k = (int)p.min_seed_len;
@@ -423,41 +422,48 @@ __global__ __launch_bounds__(256) void seed_fill_kernel(SeedParams p) {
   const int pos = c * PROBE_STRIDE + j;
   if (pos >= min(c * PROBE_STRIDE + PROBE_STRIDE, npos - 1)) return;
   int d = 0;
-  uint32_t lo = 0, hi = 0;
+  C lo = 0, hi = 0;
   ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
-  const uint64_t item = read * P + (uint64_t)pos;
+  const uint64_t item = ms_row(r0, read) + (uint64_t)pos;
   p.ms_end[item] = (uint16_t)((d >= k) ? pos + d : 0);
   p.ms_lo[item] = lo;
   p.ms_hi[item] = hi;
 }
 
-// per read: SMEM selection and ordering, one read per wavefront
-__global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
+// per read: SMEM selection and ordering, one read per wavefront.  The per-read lists (one entry per
+// position at most) live in LDS, or -- GS, reads of thousands of bases -- in a wave-private scratch in
+// global memory.  `lcap` = list capacity (longest read of the class, rounded).
+template <class C, bool GS>
+__global__ __launch_bounds__(256) void seed_select_kernel(SeedParamsT<C> p, const unsigned long long* sel_list,
+                                                          const unsigned long long* sel_count, unsigned int* queue, uint32_t lcap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
-  const uint32_t lcap = (p.max_read_len + 31u) & ~15u;
-  const uint32_t per_wave = lcap * 16;
-  uint8_t* base = smem + (size_t)wave * per_wave;
-  uint32_t* s_lo = (uint32_t*)base;            // lcap * 4
-  uint32_t* s_hi = s_lo + lcap;                // lcap * 4
-  uint16_t* a_end = (uint16_t*)(s_hi + lcap);  // lcap * 2
+  const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+  const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
+  const size_t per_wave = (size_t)lcap * (2 * sizeof(C) + 8);
+  uint8_t* base = GS ? p.sel_scratch + (size_t)wave_global * p.sel_scratch_per_wave : smem + (size_t)wave * per_wave;
+  C* s_lo = (C*)base;                          // lcap entries
+  C* s_hi = s_lo + lcap;                       // lcap
+  uint16_t* a_end = (uint16_t*)(s_hi + lcap);  // lcap * 2 bytes
   uint16_t* s_pos = a_end + lcap;              // lcap * 2
   uint16_t* s_len = s_pos + lcap;              // lcap * 2
   uint16_t* s_em = s_len + lcap;               // lcap * 2
+  auto sync = [] {
+    if (GS)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    else
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
 
   const int k = (int)p.min_seed_len;
-  const uint32_t P = p.pos_per_read;
   unsigned long long c_smems = 0, c_hits = 0;
   constexpr unsigned QCHUNK = 8;
   unsigned q_next = 0, q_end = 0;
   // Work distribution: most reads are dealt out in fixed interleaved chunks (wave w takes chunks
   // w, w + W, ...: no atomics), the last eighth through the atomic queue so that the waves finish
   // together.  One hot word serves only ~88 M returning atomics per second.
-  const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
-  const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
-  // only the reads seed_first_kernel put on the work list are left to do
-  const unsigned n_work = (unsigned)uload(p.sel_count);
+  const unsigned n_work = (unsigned)uload(sel_count);
   const unsigned n_static_chunks = (unsigned)(((unsigned long long)n_work * 7 / 8) / QCHUNK / n_waves) * n_waves;
   unsigned s_chunk = wave_global;
   unsigned long long pool_off = 0;
@@ -470,44 +476,40 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
         s_chunk += n_waves;
       } else {
         unsigned g = 0;
-        if (lane == 0) g = atomicAdd(p.queue, QCHUNK);
+        if (lane == 0) g = atomicAdd(queue, QCHUNK);
         g = n_static_chunks * QCHUNK + (unsigned)bcast_first((int)g);
         if (g >= n_work) break;
         q_next = g;
         q_end = min(g + QCHUNK, n_work);
       }
     }
-    const unsigned idx = (unsigned)uload(&p.sel_list[q_next++]);
-    const uint64_t item0 = (uint64_t)idx * P;
+    const unsigned idx = (unsigned)uload(&sel_list[q_next++]);
+    const uint64_t r0 = uload(&p.reads.offsets[idx]);
+    const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
+    const uint64_t item0 = ms_row(r0, idx);
+    const int npos = max(L - k + 1, 0);  // positions that were probed
     // Everything that depends only on the read index is requested at once (one memory round
-    // trip): the read's offsets and, for up to 128 positions, its whole row of ends and
-    // intervals; longer rows take the intervals of the SMEM starts in a second trip.
-    const bool row_in_regs = P <= 128u;
+    // trip): for up to 128 positions the whole row of ends and intervals; longer rows take the
+    // intervals of the SMEM starts in a second trip.
+    const bool row_in_regs = npos <= 128;
     uint16_t e_r[2] = {0, 0};
-    uint32_t lo_r[2] = {0, 0}, hi_r[2] = {0, 0};
+    C lo_r[2] = {0, 0}, hi_r[2] = {0, 0};
     if (row_in_regs) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        const uint32_t pos = (uint32_t)(j * 64 + lane);
-        if (pos < P) {
+        const int pos = j * 64 + lane;
+        if (pos < npos) {
           e_r[j] = p.ms_end[item0 + pos];
           lo_r[j] = p.ms_lo[item0 + pos];
           hi_r[j] = p.ms_hi[item0 + pos];
+          a_end[pos] = e_r[j];
         }
       }
-    }
-    const uint64_t r0 = uload(&p.reads.offsets[idx]);
-    const int L = (int)(uload(&p.reads.offsets[idx + 1]) - r0);
-    const int npos = max(L - k + 1, 0);  // positions that were probed
-    if (row_in_regs) {
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-        if (j * 64 + lane < npos) a_end[j * 64 + lane] = e_r[j];
     } else {
 #pragma unroll 1
       for (int t = lane; t < npos; t += 64) a_end[t] = p.ms_end[item0 + t];
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    sync();
 
     // SMEM starts: end[i] > end[i-1]; compacted in start order
     int n_sm = 0;
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
       }
       n_sm += __popcll(mask);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    sync();
 
     // emission order of FMDIndex::all_smems: walk i0; the SMEMs covering i0 come
     // out by descending start; i0 jumps to the furthest end (or to the next start)
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
     } else if (lane == 0) {
       s_em[0] = 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    sync();
     // order: length descending, then emission index descending
     // the SMEM pool is handed out to waves in slices (one atomic per slice: a single
     // hot word serves only ~88 M returning atomics per second)
@@ -584,12 +586,12 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
           rank += (lu > len || (lu == len && eu > em)) ? 1 : 0;
         }
         if (fits) {
-          Smem s;
-          s.lo = s_lo[t];
-          s.hi = s_hi[t];
-          s.qpos = s_pos[t];
-          s.len = (uint16_t)len;
-          p.smems[base_out + rank] = s;
+          SmemT<C> sm;
+          sm.lo = s_lo[t];
+          sm.hi = s_hi[t];
+          sm.qpos = s_pos[t];
+          sm.len = (uint16_t)len;
+          p.smems[base_out + rank] = sm;
         }
         hits += (unsigned long long)(s_hi[t] - s_lo[t]);
       }
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
     }
     c_smems += (unsigned long long)n_sm;
     c_hits += hits;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    sync();
   }
   if (lane == 0 && (c_smems | c_hits)) {
     atomicAdd(&p.counters[THM_CNT_SMEMS], c_smems);
@@ -613,33 +615,34 @@ __global__ __launch_bounds__(256) void seed_select_kernel(SeedParams p) {
 }
 
 // SMEM selection and ordering with one read per THREAD, for the usual case of a handful of SMEMs in
-// a read of at most 255 bases: the work per read is a few hundred instructions behind a chain of
+// a read of at most SHORT_READ_MAX bases: the work per read is a few hundred instructions behind a chain of
 // dependent loads, so the number of reads in flight is what counts (a wavefront per read leaves the
 // machine waiting).  A read with more than SEL_CAP SMEMs goes on a list for seed_select_kernel.
 constexpr int SEL_CAP = 6;
 
-__global__ __launch_bounds__(256) void seed_select_thread_kernel(SeedParams p) {
+template <class C>
+__global__ __launch_bounds__(256) void seed_select_thread_kernel(SeedParamsT<C> p, unsigned long long* over_list,
+                                                                 unsigned long long* over_count) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const unsigned T = blockDim.x, tid = threadIdx.x;
-  uint32_t* l_lo = (uint32_t*)smem;             // [SEL_CAP][T]: conflict-free for a wave
-  uint32_t* l_hi = l_lo + (size_t)SEL_CAP * T;  // [SEL_CAP][T]
-  uint32_t* l_pl = l_hi + (size_t)SEL_CAP * T;  // [SEL_CAP][T]: pos | len << 8 | emission index << 16
+  C* l_lo = (C*)smem;                    // [SEL_CAP][T]: conflict-free for a wave
+  C* l_hi = l_lo + (size_t)SEL_CAP * T;  // [SEL_CAP][T]
+  uint32_t* l_pl = (uint32_t*)(l_hi + (size_t)SEL_CAP * T);  // [SEL_CAP][T]: pos | len << 8 | emission index << 16
   const int lane = lane_id();
   const uint64_t wi = (uint64_t)blockIdx.x * T + tid;
   const bool active = wi < p.work_counts[0];
-  const uint32_t P = p.pos_per_read;
   const int k = (int)p.min_seed_len;
   int n_sm = 0;
   bool overflow = false;
   uint64_t read = 0;
   if (active) {
-    read = p.work_reads[wi];
+    read = p.work_short[wi];
     const uint64_t r0 = p.reads.offsets[read];
     const int L = (int)(p.reads.offsets[read + 1] - r0);
     const int npos = max(L - k + 1, 0);
-    const uint64_t item0 = read * P;
+    const uint64_t item0 = ms_row(r0, read);
     int prev = 0;
-    // the row of ends, eight positions (16 bytes) per load: rows are 16-byte aligned (the stride is a multiple of 8)
+    // the row of ends, eight positions (16 bytes) per load: rows start on a multiple of 8 slots
     const uint4* row = (const uint4*)(p.ms_end + item0);
     for (int c0 = 0; c0 < npos; c0 += 8) {
       const uint4 v = row[c0 >> 3];
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(256) void seed_select_thread_kernel(SeedParams p) {
     }
     if (overflow) n_sm = 0;
   }
-  block_append(overflow, read, p.sel_list_out, p.sel_count_out);
+  block_append(overflow, read, over_list, over_count);
 
   // emission order of FMDIndex::all_smems over the read's SMEMs (in start order), as in seed_select_kernel
   if (n_sm > 1) {
@@ -704,9 +707,9 @@ __global__ __launch_bounds__(256) void seed_select_thread_kernel(SeedParams p) {
       const int lu = (int)((b >> 8) & 0xffu), eu = (int)(b >> 16);
       rank += (lu > len || (lu == len && eu > em)) ? 1 : 0;
     }
-    const uint32_t slo = l_lo[(size_t)t * T + tid], shi = l_hi[(size_t)t * T + tid];
+    const C slo = l_lo[(size_t)t * T + tid], shi = l_hi[(size_t)t * T + tid];
     if (fits) {
-      Smem sm;
+      SmemT<C> sm;
       sm.lo = slo;
       sm.hi = shi;
       sm.qpos = (uint16_t)(a & 0xffu);
@@ -734,15 +737,31 @@ __global__ __launch_bounds__(256) void seed_select_thread_kernel(SeedParams p) {
   }
 }
 
-// reads with many seed hits, for the extend kernel's longest-jobs-first pass
-__global__ __launch_bounds__(256) void plan_heavy_kernel(const uint64_t* read_hits, uint64_t n_reads, unsigned long long* heavy,
-                                                         unsigned long long* count) {
+// After the seed stage: the extend stage's lists.  Reads of the fast class with many seed hits (longest
+// jobs first), reads of the slow class (band or length beyond the register-resident kernels), and the
+// status of reads no kernel takes.
+__global__ __launch_bounds__(256) void plan_kernel(PlanParams p) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  block_append(r < n_reads && read_hits[r] >= HEAVY_HITS, r, heavy, count);
+  const bool active = r < p.n_reads;
+  uint64_t L = 0, hits = 0;
+  if (active) {
+    L = p.offsets[r + 1] - p.offsets[r];
+    hits = p.read_hits[r];
+  }
+  const bool fast = active && L <= p.fast_max_len;
+  const bool slow = active && !fast && L <= p.slow_max_len;
+  if (active && !fast && !slow) {
+    p.read_status[r] = THM_ERR_UNSUPPORTED;
+    p.read_n_alns[r] = 0;
+    p.read_op_bytes[r] = 0;
+  }
+  block_append(fast && hits >= HEAVY_HITS, r, p.heavy, &p.counts[2]);
+  block_append(slow, r, p.slow, &p.counts[5]);
 }
 
 // Mem list of Index::all_smems for thm_smems_batch: one wave per read
-__global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
+template <class C>
+__global__ __launch_bounds__(256) void expand_kernel(ExpandParamsT<C> p) {
   const int lane = lane_id();
   const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= p.n_reads) return;
@@ -750,9 +769,9 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
   const uint32_t ns = p.read_smem_cnt[r];
   uint64_t out = p.read_mem_off[r];
   for (uint32_t s = 0; s < ns; s++) {
-    const Smem sm = p.smems[s0 + s];
-    const uint32_t cnt = sm.hi - sm.lo;
-    for (uint32_t t = lane; t < cnt; t += 64) {
+    const SmemT<C> sm = p.smems[s0 + s];
+    const uint64_t cnt = (uint64_t)(sm.hi - sm.lo);
+    for (uint64_t t = lane; t < cnt; t += 64) {
       thm_mem m;
       m.ref_idx = p.ix.sa[sm.hi - 1 - t];
       m.query_idx = sm.qpos;
@@ -765,10 +784,10 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
 
 }  // namespace dev
 
-size_t seed_lds_bytes(uint32_t max_read_len) {
-  const uint32_t lcap = (max_read_len + 31u) & ~15u;
-  return 4 * (size_t)lcap * 16;
-}
+static uint32_t sel_lcap(uint32_t max_read_len) { return (max_read_len + 31u) & ~15u; }
+// lists of the wavefront-per-read selection: per position 2 intervals bounds + 4 u16 (sized for the wide coordinates)
+size_t seed_select_scratch_bytes(uint32_t max_read_len) { return (size_t)sel_lcap(max_read_len) * (2 * 8 + 8); }
+size_t seed_select_lds_bytes(uint32_t max_read_len) { return 4 * seed_select_scratch_bytes(max_read_len); }
 
 hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded, hipStream_t s) {
   if (n_padded == 0) return hipSuccess;
@@ -776,63 +795,86 @@ hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t
   return hipGetLastError();
 }
 
-hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s) {
+template <class C>
+static hipError_t launch_seed_t(const SeedParamsT<C>& p, int n_blocks, hipStream_t s) {
   const uint64_t n = p.reads.n_reads;
-  if (n) {
-    const uint32_t P = p.pos_per_read;
-    const uint64_t G = (P + dev::PROBE_STRIDE - 1) / dev::PROBE_STRIDE + 1, C = (P + dev::PROBE_STRIDE - 1) / dev::PROBE_STRIDE;
-    auto blocks = [](uint64_t threads) { return dim3((unsigned)((threads + 255) / 256)); };
-    hipLaunchKernelGGL(dev::seed_first_kernel, blocks(n), dim3(256), 0, s, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (P > 1) {
-      // grids sized for the worst case; threads past the work-list counts (device memory) leave at once
-      hipLaunchKernelGGL(dev::seed_grid_kernel, blocks(n * G), dim3(256), 0, s, p);
-      if ((e = hipGetLastError()) != hipSuccess) return e;
-      hipLaunchKernelGGL(dev::seed_cells_kernel, blocks(n * C), dim3(256), 0, s, p);
-      if ((e = hipGetLastError()) != hipSuccess) return e;
-      hipLaunchKernelGGL(dev::seed_fill_kernel, blocks(n * C * dev::PROBE_STRIDE), dim3(256), 0, s, p);
-      if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (n == 0) return hipSuccess;
+  const uint32_t k = p.min_seed_len;
+  auto blocks = [](uint64_t threads) { return dim3((unsigned)((threads + 255) / 256)); };
+  auto cells_of = [&](uint32_t max_len) -> uint64_t {  // grid cells per read of a class
+    const uint32_t P = (max_len >= k) ? max_len - k + 1 : 1;
+    return (P + dev::PROBE_STRIDE - 1) / dev::PROBE_STRIDE;
+  };
+  hipError_t e;
+  hipLaunchKernelGGL(dev::seed_first_kernel<C>, blocks(n), dim3(256), 0, s, p);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  const uint64_t n_short = n - p.n_long;
+  // grids sized for the worst case; threads past the work-list counts (device memory) leave at once
+  struct Cls {
+    uint64_t n;
+    uint32_t max_len;
+    const unsigned long long* list;
+    const unsigned long long* count;
+  } cls[2] = {{n_short, p.max_len_short, p.work_short, p.work_counts + 0}, {p.n_long, p.max_len_long, p.work_long, p.work_counts + 4}};
+  uint64_t fill_cells = 0;
+  for (const Cls& c : cls) {
+    if (c.n == 0 || c.max_len < k + 1) continue;  // a single position was probed by seed_first_kernel
+    const uint64_t NC = cells_of(c.max_len), G = NC + 1;
+    hipLaunchKernelGGL(dev::seed_grid_kernel<C>, blocks(c.n * G), dim3(256), 0, s, p, c.list, c.count, (uint32_t)G);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(dev::seed_cells_kernel<C>, blocks(c.n * NC), dim3(256), 0, s, p, c.list, c.count, (uint32_t)NC);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    fill_cells += c.n * NC;
+  }
+  if (fill_cells) {
+    hipLaunchKernelGGL(dev::seed_fill_kernel<C>, blocks(fill_cells * dev::PROBE_STRIDE), dim3(256), 0, s, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  // SMEM selection: short reads one per thread, its overflow list and the long reads through the
+  // wavefront-per-read kernel
+  auto select_waves = [&](const unsigned long long* list, const unsigned long long* count, unsigned int* queue, uint32_t max_len,
+                          int nb) -> hipError_t {
+    const uint32_t lcap = sel_lcap(max_len);
+    const size_t lds = 4 * (size_t)lcap * (2 * sizeof(C) + 8);
+    if (lds <= SEED_SELECT_LDS_LIMIT) {
+      hipLaunchKernelGGL((dev::seed_select_kernel<C, false>), dim3(nb), dim3(256), lds, s, p, list, count, queue, lcap);
+    } else {
+      hipLaunchKernelGGL((dev::seed_select_kernel<C, true>), dim3(nb), dim3(256), 0, s, p, list, count, queue, lcap);
     }
+    return hipGetLastError();
+  };
+  if (n_short) {
+    unsigned long long* over_list = p.work_cells;  // free again: seed_fill_kernel is done with it
+    unsigned long long* over_count = p.work_counts + 3;
+    hipLaunchKernelGGL(dev::seed_select_thread_kernel<C>, dim3((unsigned)((n_short + 255) / 256)), dim3(256),
+                       (size_t)256 * (2 * sizeof(C) + 4) * dev::SEL_CAP, s, p, over_list, over_count);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // the overflow list is short: every wave costs an atomic just to find it empty
+    if ((e = select_waves(over_list, over_count, p.queue, p.max_len_short, std::min(n_blocks, 256))) != hipSuccess) return e;
   }
-  // SMEM selection: one read per thread when positions and lengths fit a byte, its overflow list
-  // (or, for longer reads, the whole work list) through the wavefront-per-read kernel
-  SeedParams q = p;
-  if (p.max_read_len <= 255 && n) {
-    q.sel_list_out = p.work_cells;  // free again: seed_fill_kernel is done with it
-    q.sel_count_out = p.work_counts + 3;
-    hipLaunchKernelGGL(dev::seed_select_thread_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
-                       (size_t)256 * 4 * 3 * dev::SEL_CAP, s, q);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    q.sel_list = p.work_cells;
-    q.sel_count = p.work_counts + 3;
-    n_blocks = std::min(n_blocks, 256);  // the overflow list is short: every wave costs an atomic just to find it empty
-  } else {
-    q.sel_list = p.work_reads;
-    q.sel_count = p.work_counts;
+  if (p.n_long) {
+    const int nb = (int)std::min<uint64_t>((uint64_t)n_blocks, (p.n_long + 3) / 4);
+    if ((e = select_waves(p.work_long, p.work_counts + 4, p.queue + 1, p.max_len_long, std::max(nb, 1))) != hipSuccess) return e;
   }
-  const size_t lds = seed_lds_bytes(p.max_read_len);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)dev::seed_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(dev::seed_select_kernel, dim3(n_blocks), dim3(256), lds, s, q);
+  return hipSuccess;
+}
+hipError_t launch_seed(const SeedParamsT<uint32_t>& p, int n_blocks, hipStream_t s) { return launch_seed_t(p, n_blocks, s); }
+hipError_t launch_seed(const SeedParamsT<uint64_t>& p, int n_blocks, hipStream_t s) { return launch_seed_t(p, n_blocks, s); }
+
+hipError_t launch_plan(const PlanParams& p, hipStream_t s) {
+  if (p.n_reads == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::plan_kernel, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
-hipError_t launch_plan_heavy(const uint64_t* read_hits, uint64_t n_reads, unsigned long long* heavy, unsigned long long* count,
-                             hipStream_t s) {
-  if (n_reads == 0) return hipSuccess;
-  hipLaunchKernelGGL(dev::plan_heavy_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, read_hits, n_reads, heavy, count);
-  return hipGetLastError();
-}
-
-hipError_t launch_expand(const ExpandParams& p, hipStream_t s) {
+template <class C>
+static hipError_t launch_expand_t(const ExpandParamsT<C>& p, hipStream_t s) {
   const unsigned blocks = (unsigned)((p.n_reads + 3) / 4);
   if (blocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(dev::expand_kernel, dim3(blocks), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(dev::expand_kernel<C>, dim3(blocks), dim3(256), 0, s, p);
   return hipGetLastError();
 }
+hipError_t launch_expand(const ExpandParamsT<uint32_t>& p, hipStream_t s) { return launch_expand_t(p, s); }
+hipError_t launch_expand(const ExpandParamsT<uint64_t>& p, hipStream_t s) { return launch_expand_t(p, s); }
 
 }  // namespace thm

@@ -10,19 +10,68 @@
 namespace thm {
 namespace dev {
 
+// per-wave layout of the any-width variant's slice of global memory (CPL == 0)
+struct SwgSlowLayout {
+  uint64_t xs, ys, ops, dp, trace, total;
+  uint32_t dp_stride, ops_cap;
+};
+__host__ __device__ inline SwgSlowLayout swg_slow_layout(uint32_t x_cap, uint32_t y_cap, uint32_t max_bw) {
+  SwgSlowLayout s;
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) {
+    const uint64_t at = o;
+    o += (bytes + 63u) & ~63ull;
+    return at;
+  };
+  s.ops_cap = x_cap + y_cap + 16;
+  s.xs = take(x_cap);
+  s.ys = take(y_cap);
+  s.ops = take(s.ops_cap);
+  const uint32_t tiles = (2u * max_bw + 1u + 63u) / 64u;
+  s.dp_stride = tiles * 64u + 64u;
+  s.dp = take((uint64_t)s.dp_stride * 16u);
+  s.trace = take((uint64_t)(y_cap + 2u) * tiles * 16u);
+  s.total = o;
+  return s;
+}
+
+// CPL = band slots per lane (1..4), or 0: band of any width (swg_extend_tiled, buffers in global memory)
 template <int CPL>
 __global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = lane_id();
   const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
-  const uint32_t tr_bytes = (p.y_cap + 1) * CPL * 16;
-  const uint32_t ops_cap = p.x_cap + p.y_cap + 16;
-  const uint32_t per_wave = p.x_cap + p.y_cap + tr_bytes + ops_cap;
-  uint8_t* base = smem + (size_t)wave * per_wave;
-  uint8_t* xs = base;
-  uint8_t* ys = xs + p.x_cap;
-  unsigned long long* trace = (unsigned long long*)(ys + p.y_cap);
-  uint8_t* opsb = (uint8_t*)trace + tr_bytes;
+  uint8_t *xs, *ys, *opsb;
+  unsigned long long* trace;
+  int* dp = nullptr;
+  int dp_stride = 0;
+  uint32_t ops_cap;
+  if constexpr (CPL == 0) {
+    const SwgSlowLayout sl = swg_slow_layout(p.x_cap, p.y_cap, p.max_bw);
+    uint8_t* base = p.scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) * p.scratch_per_wave;
+    xs = base + sl.xs;
+    ys = base + sl.ys;
+    opsb = base + sl.ops;
+    trace = (unsigned long long*)(base + sl.trace);
+    dp = (int*)(base + sl.dp);
+    dp_stride = (int)sl.dp_stride;
+    ops_cap = sl.ops_cap;
+  } else {
+    const uint32_t tr_bytes = (p.y_cap + 1) * CPL * 16;
+    ops_cap = p.x_cap + p.y_cap + 16;
+    const uint32_t per_wave = p.x_cap + p.y_cap + tr_bytes + ops_cap;
+    uint8_t* base = smem + (size_t)wave * per_wave;
+    xs = base;
+    ys = xs + p.x_cap;
+    trace = (unsigned long long*)(ys + p.y_cap);
+    opsb = (uint8_t*)trace + tr_bytes;
+  }
+  auto sync = [] {
+    if (CPL == 0)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    else
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
 
   unsigned long long n_cells = 0, n_cols = 0, n_calls = 0;
   constexpr unsigned QCHUNK = 8;  // problems per queue atomic (a single hot word serves ~88 M atomics/s)
@@ -48,13 +97,21 @@ __global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
     for (int t = lane; t < xlen; t += 64) xs[t] = p.xb[x0 + t];
     #pragma unroll 1
     for (int t = lane; t < ylen; t += 64) ys[t] = p.yb[y0 + t];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    sync();
 
-    SwgResult r = swg_extend_wave<CPL>(xs, 1, xlen, ys, 1, ylen, bw, xd, trace);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // path from the max cell back to the origin, laid out so that it reads forward
-    int nops = swg_traceback_wave<CPL>(trace, r.xend, r.yend, bw, opsb + ops_cap - 1, -1, (int)ops_cap);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    SwgResult r;
+    int nops;
+    if constexpr (CPL == 0) {
+      r = swg_extend_tiled(xs, 1, xlen, ys, 1, ylen, bw, xd, trace, dp, dp_stride);
+      sync();
+      nops = swg_traceback_tiled(trace, r.xend, r.yend, bw, opsb + ops_cap - 1, -1, (int)ops_cap);
+    } else {
+      r = swg_extend_wave<(CPL > 0 ? CPL : 1)>(xs, 1, xlen, ys, 1, ylen, bw, xd, trace);
+      sync();
+      // path from the max cell back to the origin, laid out so that it reads forward
+      nops = swg_traceback_wave<(CPL > 0 ? CPL : 1)>(trace, r.xend, r.yend, bw, opsb + ops_cap - 1, -1, (int)ops_cap);
+    }
+    sync();
     if (nops < 0) {
       if (lane == 0) atomicExch(p.fault, 1);
       nops = 0;
@@ -109,7 +166,10 @@ __global__ void wave_prims_kernel(const int* in, int* out) {
 
 }  // namespace dev
 
+size_t swg_batch_scratch_bytes(const SwgBatchParams& p) { return (size_t)dev::swg_slow_layout(p.x_cap, p.y_cap, p.max_bw).total; }
+
 size_t swg_batch_lds_bytes(const SwgBatchParams& p, int cpl) {
+  if (cpl == 0) return 0;
   const size_t tr = (size_t)(p.y_cap + 1) * cpl * 16;
   return 4 * ((size_t)p.x_cap + p.y_cap + tr + p.x_cap + p.y_cap + 16);
 }
@@ -125,6 +185,7 @@ hipError_t launch_swg_batch(const SwgBatchParams& p, int cpl, int n_blocks, hipS
     return hipGetLastError();
   };
   switch (cpl) {
+    case 0: return go(dev::swg_batch_kernel<0>);
     case 1: return go(dev::swg_batch_kernel<1>);
     case 2: return go(dev::swg_batch_kernel<2>);
     case 3: return go(dev::swg_batch_kernel<3>);

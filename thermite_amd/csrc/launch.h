@@ -1,4 +1,8 @@
 // launch.h -- kernel parameter blocks and host-callable launch wrappers.
+//
+// Everything that holds a text position or a suffix-array rank is templated on the
+// coordinate type C (uint32_t / uint64_t, see thermite_internal.h "Coordinate width");
+// the launch wrappers are overloaded on it.
 #ifndef THERMITE_LAUNCH_H
 #define THERMITE_LAUNCH_H
 
@@ -22,9 +26,14 @@ struct SwgBatchParams {
   unsigned int* queue;           // work-queue head, zeroed before launch
   int* fault;
   uint64_t n;
-  uint32_t x_cap, y_cap;  // per-wave LDS bytes for x and y (multiples of 16)
+  uint32_t x_cap, y_cap;  // per-wave bytes for x and y (multiples of 16)
+  // cpl == 0 (band of any width, swg_extend_tiled): per-wave scratch in global memory
+  uint8_t* scratch;         // [waves in the grid * scratch_per_wave]
+  uint64_t scratch_per_wave;
+  uint32_t max_bw;          // sizes the tiled trace and the column state
 };
 size_t swg_batch_lds_bytes(const SwgBatchParams& p, int cpl);
+size_t swg_batch_scratch_bytes(const SwgBatchParams& p);  // per wave, cpl == 0
 hipError_t launch_swg_batch(const SwgBatchParams& p, int cpl, int n_blocks, hipStream_t s);
 hipError_t launch_wave_prims(const int* in, int* out, hipStream_t s);
 
@@ -35,50 +44,82 @@ struct ReadBatch {
   uint64_t n_reads;
 };
 
-struct SeedParams {
-  DeviceIndex ix;
+// Longest read the 16-bit fields of the seed stage hold (ends and lengths); longer reads get the per-read
+// status THM_ERR_UNSUPPORTED and no alignments.
+constexpr uint32_t MAX_READ_LEN = 65535;
+// Reads up to this length take the byte-per-position paths of the seed stage ("short"); longer ones ("long")
+// are listed separately so that a few long reads in a batch of short ones do not size anybody else's launch.
+constexpr uint32_t SHORT_READ_MAX = 255;
+
+// Row of read r in the per-position arrays of the seed stage (ends and intervals of the matching statistics):
+// ragged, 8-slot aligned, one slot per base of the read.
+__host__ __device__ inline uint64_t ms_row(uint64_t base_off, uint64_t r) { return (base_off + 8 * r) & ~7ull; }
+
+template <class C>
+struct SeedParamsT {
+  DeviceIndexT<C> ix;
   ReadBatch reads;
   uint32_t min_seed_len;
-  uint32_t max_read_len;       // LDS sizing
-  uint32_t pos_per_read;       // probe slots per read: max_read_len - min_seed_len + 1 (>= 1) rounded up to 8; the row stride
-  uint16_t* ms_end;            // [n_reads * pos_per_read] end of the longest match from this position (0: < k)
-  uint32_t* ms_lo;             // its suffix-array interval
-  uint32_t* ms_hi;
-  unsigned long long* work_reads;   // [n_reads] reads that need more than the probe at position 0
-  unsigned long long* work_cells;   // [n_reads * cells per read] (read << 16 | cell) of grid cells to probe
-  unsigned long long* work_counts;  // [4] list lengths ([2]: heavy reads, [3]: select overflow), zeroed before launch
-  const unsigned long long* sel_list;   // reads seed_select_kernel goes through, and how many (set by launch_seed)
-  const unsigned long long* sel_count;
-  unsigned long long* sel_list_out;     // seed_select_thread_kernel: reads with more SMEMs than its list holds
-  unsigned long long* sel_count_out;
-  Smem* smems;                 // pool
+  uint32_t max_len_short;  // longest read of at most SHORT_READ_MAX bases in the batch (0: none)
+  uint32_t max_len_long;   // longest read above SHORT_READ_MAX (0: none), at most MAX_READ_LEN
+  uint64_t n_long;         // reads above SHORT_READ_MAX (host count: sizes the launches of the long class)
+  uint16_t* ms_end;        // [ms_row(n_bases, n_reads)] end of the longest match from this position (0: < k)
+  C* ms_lo;                // its suffix-array interval
+  C* ms_hi;
+  unsigned long long* work_short;   // [n_reads] short reads that need more than the probe at position 0
+  unsigned long long* work_long;    // [n_long] long reads, the same
+  unsigned long long* work_cells;   // [cells] (read << 16 | cell) of grid cells to probe
+  unsigned long long* work_counts;  // [8] list lengths: 0 short, 1 cells, 2 heavy, 3 select overflow, 4 long, 5 slow; zeroed before launch
+  SmemT<C>* smems;             // pool
   uint64_t smem_cap;           // pool capacity (entries)
   unsigned long long* cursor;  // bump allocator head (entries), zeroed before launch
   uint64_t* read_smem_off;     // [n_reads] first entry of the read's run in the pool
   uint32_t* read_smem_cnt;     // [n_reads]
   uint64_t* read_hits;         // [n_reads] total occurrences = sum(hi-lo)
+  int32_t* read_status;        // [n_reads] per-read status (0 ok), zeroed before launch
   unsigned long long* counters;
-  unsigned int* queue;
+  unsigned int* queue;         // two words: one per launch of the wavefront-per-read selection kernel
   int* fault;  // 1 = smem pool overflow
+  uint8_t* sel_scratch;        // global scratch of the wavefront-per-read selection when its lists do not fit LDS
+  uint64_t sel_scratch_per_wave;
 };
-size_t seed_lds_bytes(uint32_t max_read_len);
-hipError_t launch_seed(const SeedParams& p, int n_blocks, hipStream_t s);
-// list the reads with >= HEAVY_HITS hits (after the seed stage): heavy[0 .. *count)
-hipError_t launch_plan_heavy(const uint64_t* read_hits, uint64_t n_reads, unsigned long long* heavy, unsigned long long* count,
-                             hipStream_t s);
+size_t seed_select_lds_bytes(uint32_t max_read_len);         // per workgroup (4 waves)
+size_t seed_select_scratch_bytes(uint32_t max_read_len);     // per wave
+constexpr size_t SEED_SELECT_LDS_LIMIT = 64 * 1024;          // above this the lists go to global scratch
+hipError_t launch_seed(const SeedParamsT<uint32_t>& p, int n_blocks, hipStream_t s);
+hipError_t launch_seed(const SeedParamsT<uint64_t>& p, int n_blocks, hipStream_t s);
 hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded, hipStream_t s);
 
-// expand SMEMs into Mem lists (thm_smems_batch)
-struct ExpandParams {
-  DeviceIndex ix;
+// After the seed stage: list the reads of the fast class with >= HEAVY_HITS hits (heavy[0 .. counts[2])), the reads
+// of the slow class (slow[0 .. counts[5])), and give reads beyond every class their status.
+struct PlanParams {
+  const uint64_t* offsets;
+  const uint64_t* read_hits;
   uint64_t n_reads;
-  const Smem* smems;
+  uint32_t fast_max_len;  // reads up to this length run in the register-resident extend kernel
+  uint32_t slow_max_len;  // longer ones up to this length in the any-width kernel; beyond: THM_ERR_UNSUPPORTED
+  unsigned long long* heavy;
+  unsigned long long* slow;
+  unsigned long long* counts;  // work_counts of the seed stage
+  int32_t* read_status;
+  uint32_t* read_n_alns;       // zeroed for unsupported reads
+  uint64_t* read_op_bytes;
+};
+hipError_t launch_plan(const PlanParams& p, hipStream_t s);
+
+// expand SMEMs into Mem lists (thm_smems_batch)
+template <class C>
+struct ExpandParamsT {
+  DeviceIndexT<C> ix;
+  uint64_t n_reads;
+  const SmemT<C>* smems;
   const uint64_t* read_smem_off;
   const uint32_t* read_smem_cnt;
   const uint64_t* read_mem_off;  // exclusive prefix sum of read_hits, [n_reads+1]
   thm_mem* mems;
 };
-hipError_t launch_expand(const ExpandParams& p, hipStream_t s);
+hipError_t launch_expand(const ExpandParamsT<uint32_t>& p, hipStream_t s);
+hipError_t launch_expand(const ExpandParamsT<uint64_t>& p, hipStream_t s);
 
 // exclusive prefix sum of u64 (n entries -> n+1 entries), single launch for moderate n
 hipError_t launch_exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* block_tmp,
@@ -104,19 +145,23 @@ struct Cand {
 
 // work counters of the extend kernel: EXT_NQ of them, EXT_QSTRIDE u32 apart (separate cache lines)
 constexpr unsigned EXT_NQ = 8, EXT_QSTRIDE = 64;
-constexpr size_t QUEUE_BYTES = (EXT_NQ + 1) * EXT_QSTRIDE * 4;  // + the counter of the heavy-read list
+constexpr size_t QUEUE_BYTES = (EXT_NQ + 2) * EXT_QSTRIDE * 4;  // + the counter of the heavy-read list + the one of the slow list
 constexpr unsigned HEAVY_HITS = 8;  // reads with at least this many seed hits are scheduled first
+// intron markers one alignment can carry in the register-resident kernel (LDS); an alignment across more
+// introns sends its read to the any-width kernel, whose marker list is sized by the longest transcript
+constexpr int FAST_MAX_YCLIPS = 64;
 
-struct ExtendParams {
-  DeviceIndex ix;
+template <class C>
+struct ExtendParamsT {
+  DeviceIndexT<C> ix;
   ReadBatch reads;
   thm_align_opts opts;
-  const Smem* smems;
+  const SmemT<C>* smems;
   const uint64_t* read_smem_off;
   const uint32_t* read_smem_cnt;
   const uint64_t* read_cand_off;  // exclusive prefix sum of read_hits: the read's slice of cands[]
-  const unsigned long long* heavy;        // reads with >= HEAVY_HITS hits (plan_heavy_kernel)
-  const unsigned long long* heavy_count;  // [1]
+  const unsigned long long* heavy;        // the list this launch goes through first: reads with >= HEAVY_HITS hits
+  const unsigned long long* heavy_count;  // (fast kernel) or the reads of the slow class and the retries (any-width kernel)
   Cand* cands;
   uint64_t cand_cap;  // entries in cands[] (order[] holds twice as many u32)
   uint32_t* order;  // [total hits] per-read scratch for the final ordering (indices into the read's slice)
@@ -125,18 +170,29 @@ struct ExtendParams {
   unsigned long long* ops_cursor;
   uint32_t* read_n_alns;      // [n_reads] final alignment count
   uint64_t* read_op_bytes;    // [n_reads] serialised op bytes of the final alignments
+  int32_t* read_status;       // [n_reads]
+  unsigned long long* retry;        // fast kernel: reads it could not finish (intron markers), appended to the slow list
+  unsigned long long* retry_count;
+  unsigned long long* n_contract;   // reads that ended with THM_ERR_OUT_OF_CONTRACT (tells the host to fetch the statuses)
   unsigned long long* counters;
   unsigned int* queue;
-  int* fault;  // bit 0: op pool overflow, bit 1: internal inconsistency, bit 2: out-of-contract (lift failure)
+  int* fault;  // bit 0: op pool overflow, bit 1: internal inconsistency
   const int* fault_seed;  // set by the seed kernels on an SMEM pool overflow: the SMEM runs are incomplete, nothing may be read
-  uint32_t max_read_len;
+  uint32_t max_read_len;  // reads of this launch are at most this long (the fast kernel skips longer ones)
   uint32_t max_bw;
-  unsigned long long* trace_scratch;  // [waves in the grid * extend_trace_scratch_bytes / 8] (unused when cpl == 1)
+  uint32_t mk_cap;        // intron markers per alignment
+  uint32_t list_only;     // 1: only the reads of the list (any-width kernel)
+  unsigned long long* trace_scratch;  // fast kernel: [waves in the grid * extend_trace_scratch_bytes / 8] (unused when cpl == 1)
+  uint8_t* slow_scratch;              // any-width kernel: [waves in the grid * slow_scratch_per_wave]
+  uint64_t slow_scratch_per_wave;
   unsigned long long* prof;  // 16 slots of shader clocks per section (THM_PROF builds), else unused
 };
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
 size_t extend_trace_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
-hipError_t launch_extend(const ExtendParams& p, int cpl, int n_blocks, hipStream_t s);
+size_t extend_slow_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, uint32_t mk_cap);  // per wave
+constexpr size_t EXTEND_LDS_LIMIT = 160 * 1024;  // gfx950: one workgroup may take the whole LDS of its CU
+hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s);
+hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s);
 
 struct CompactParams {
   uint64_t n_reads;

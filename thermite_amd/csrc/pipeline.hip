@@ -3,10 +3,13 @@
 //   thm_align_batch (= the three in sequence) and thm_smems_batch.
 //
 // One batch = count -> scan -> fill on the device:
-//   seed kernels    SMEMs per read (pool + per-read run), hit counts, list of reads with many hits
+//   seed kernels    SMEMs per read (pool + per-read run), hit counts
+//   plan kernel     lists: reads with many hits (longest jobs first), reads of the slow class
 //   scan            hit counts -> per-read slice of the candidate array
 //   extend kernel   align_read per read; accepted alignments into the slice,
-//                   op streams into a bump-allocated pool; final order list
+//                   op streams into a bump-allocated pool; final order list.
+//                   Reads whose band or length exceeds what the register-resident kernel
+//                   holds (the slow class) run afterwards in the any-width kernel.
 //   scans           alignment counts / op bytes -> output offsets
 //   compact kernel  canonical output (alignments in read order, op streams
 //                   back to back), so the D2H copy is a plain memcpy
@@ -40,7 +43,22 @@ int blocks_for(const thm_aligner* a, uint64_t n, size_t lds_per_block) {
   return grid_blocks(a, n, 4, per_cu);
 }
 
-int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
+// device memory the any-width kernel may take for its wave-private buffers (traces grow with length x band)
+constexpr uint64_t SLOW_SCRATCH_BUDGET = 24ull << 30;
+
+template <class C>
+const DeviceIndexT<C>& dev_view(const thm_aligner* a);
+template <>
+const DeviceIndexT<uint32_t>& dev_view<uint32_t>(const thm_aligner* a) {
+  return a->dix->view;
+}
+template <>
+const DeviceIndexT<uint64_t>& dev_view<uint64_t>(const thm_aligner* a) {
+  return a->dix->view64;
+}
+
+template <class C>
+int enqueue_seed_t(thm_aligner* a, uint32_t min_seed_len) {
   const uint64_t n = a->n_reads;
   hipStream_t s = a->stream;
   HIPCHK(a, a->s_off.ensure((n + 1) * 8));
@@ -48,70 +66,197 @@ int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
   HIPCHK(a, a->s_hits.ensure((n + 1) * 8));
   HIPCHK(a, a->s_cand_off.ensure((n + 2) * 8));
   HIPCHK(a, a->scan_tmp.ensure(scan_tmp_entries(n + 1) * 8 + 64));
+  HIPCHK(a, a->r_status.ensure((n + 1) * 4));
+  HIPCHK(a, hipMemsetAsync(a->r_status.p, 0, (n + 1) * 4, s));
   // typical: 1-2 SMEMs per read; waves take the pool in 256-entry slices, hence the fixed slack
   const uint64_t smem_min = a->dbg_smem_cap ? a->dbg_smem_cap : n * 4 + (4u << 20);
   if (a->smem_cap < smem_min) a->smem_cap = smem_min;
-  HIPCHK(a, a->s_smems.ensure(a->smem_cap * sizeof(Smem)));
-  if (!a->dbg_smem_cap) a->smem_cap = std::max<uint64_t>(a->smem_cap, a->s_smems.cap / sizeof(Smem));
+  HIPCHK(a, a->s_smems.ensure(a->smem_cap * sizeof(SmemT<C>)));
+  if (!a->dbg_smem_cap) a->smem_cap = std::max<uint64_t>(a->smem_cap, a->s_smems.cap / sizeof(SmemT<C>));
   // to_ascii_uppercase (src/aligner.rs:125) + sanitising, once per run for both kernels
   HIPCHK(a, a->r_san.ensure(a->n_bases + 256));
   HIPCHK(a, launch_sanitize(a->r_bases.as<uint8_t>(), a->r_san.as<uint8_t>(), a->n_bases, a->n_bases + 128, s));
-  // probe slots per read, rounded up to 8 so that a read's row of ends starts on a 16-byte boundary
-  const uint32_t P = (((a->max_read_len >= min_seed_len) ? a->max_read_len - min_seed_len + 1 : 1) + 7u) & ~7u;
-  const uint64_t items = n * (uint64_t)P;
+  // length classes of the seed stage (launch.h): short reads take the byte-per-position paths
+  uint64_t n_long = 0;
+  uint32_t max_short = 0, max_long = 0;
+  for (const auto& lc : a->len_hist) {
+    if (lc.first <= SHORT_READ_MAX) {
+      max_short = std::max(max_short, lc.first);
+    } else {
+      max_long = std::max(max_long, lc.first);
+      n_long += lc.second;
+    }
+  }
+  const uint64_t n_short = n - n_long;
+  // ragged per-position rows (launch.h, ms_row)
+  const uint64_t items = ms_row(a->n_bases, n) + 64;
   HIPCHK(a, a->s_ms_end.ensure(items * 2 + 64));
-  HIPCHK(a, a->s_ms_lo.ensure(items * 4 + 64));
-  HIPCHK(a, a->s_ms_hi.ensure(items * 4 + 64));
+  HIPCHK(a, a->s_ms_lo.ensure(items * sizeof(C) + 64));
+  HIPCHK(a, a->s_ms_hi.ensure(items * sizeof(C) + 64));
+  auto cells_of = [&](uint32_t max_len) -> uint64_t {
+    const uint32_t P = (max_len >= min_seed_len) ? max_len - min_seed_len + 1 : 1;
+    return (P + 7) / 8;
+  };
+  const uint64_t cells = n_short * cells_of(max_short) + n_long * cells_of(max_long);
   HIPCHK(a, a->s_work_reads.ensure((n + 1) * 8));
-  HIPCHK(a, a->s_work_cells.ensure((n * (uint64_t)((P + 7) / 8) + 1) * 8));
+  HIPCHK(a, a->s_work_long.ensure((n_long + 1) * 8));
+  HIPCHK(a, a->s_work_cells.ensure((std::max(cells, n) + 1) * 8));
   HIPCHK(a, a->s_work_counts.ensure(64));
   HIPCHK(a, hipMemsetAsync(a->s_work_counts.p, 0, 64, s));
   int rc = reset_queue(a);
   if (rc != THM_OK) return rc;
   HIPCHK(a, hipMemsetAsync(a->d_cursors.p, 0, 64, s));
-  SeedParams sp;
-  sp.ix = a->dix->view;
-  sp.pos_per_read = P;
-  sp.ms_end = a->s_ms_end.as<uint16_t>();
-  sp.ms_lo = a->s_ms_lo.as<uint32_t>();
-  sp.ms_hi = a->s_ms_hi.as<uint32_t>();
-  sp.work_reads = a->s_work_reads.as<unsigned long long>();
-  sp.work_cells = a->s_work_cells.as<unsigned long long>();
-  sp.work_counts = a->s_work_counts.as<unsigned long long>();
+  const int n_blocks = blocks_for(a, n, std::min(seed_select_lds_bytes(std::max(max_short, 1u)), SEED_SELECT_LDS_LIMIT));
+  SeedParamsT<C> sp;
+  sp.ix = dev_view<C>(a);
   sp.reads.bases = a->r_san.as<uint8_t>();
   sp.reads.offsets = a->r_offsets.as<uint64_t>();
   sp.reads.n_reads = n;
   sp.min_seed_len = min_seed_len;
-  sp.max_read_len = a->max_read_len;
-  sp.smems = a->s_smems.as<Smem>();
+  sp.max_len_short = max_short;
+  sp.max_len_long = max_long;
+  sp.n_long = n_long;
+  sp.ms_end = a->s_ms_end.as<uint16_t>();
+  sp.ms_lo = a->s_ms_lo.as<C>();
+  sp.ms_hi = a->s_ms_hi.as<C>();
+  sp.work_short = a->s_work_reads.as<unsigned long long>();
+  sp.work_long = a->s_work_long.as<unsigned long long>();
+  sp.work_cells = a->s_work_cells.as<unsigned long long>();
+  sp.work_counts = a->s_work_counts.as<unsigned long long>();
+  sp.smems = a->s_smems.as<SmemT<C>>();
   sp.smem_cap = a->smem_cap;
   sp.cursor = a->d_cursors.as<unsigned long long>();
   sp.read_smem_off = a->s_off.as<uint64_t>();
   sp.read_smem_cnt = a->s_cnt.as<uint32_t>();
   sp.read_hits = a->s_hits.as<uint64_t>();
+  sp.read_status = a->r_status.as<int32_t>();
   sp.counters = a->d_counters.as<unsigned long long>();
   sp.queue = a->d_queue.as<unsigned int>();
   sp.fault = a->d_fault.as<int>();
-  HIPCHK(a, launch_seed(sp, blocks_for(a, n, seed_lds_bytes(a->max_read_len)), s));
-  // reads with many hits, for the extend kernel's first pass (s_work_reads is free again: the seed kernels are done with it)
-  HIPCHK(a, launch_plan_heavy(a->s_hits.as<uint64_t>(), n, a->s_work_reads.as<unsigned long long>(),
-                              a->s_work_counts.as<unsigned long long>() + 2, s));
+  sp.sel_scratch = nullptr;
+  sp.sel_scratch_per_wave = 0;
+  if (n_long && seed_select_lds_bytes(max_long) > SEED_SELECT_LDS_LIMIT) {
+    // reads of thousands of bases: the selection kernel's per-read lists go to global memory
+    const int nb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_blocks, (n_long + 3) / 4));
+    sp.sel_scratch_per_wave = (seed_select_scratch_bytes(max_long) + 255) & ~255ull;
+    HIPCHK(a, a->s_sel_scratch.ensure((size_t)nb * 4 * sp.sel_scratch_per_wave + 256));
+    sp.sel_scratch = a->s_sel_scratch.as<uint8_t>();
+  }
+  HIPCHK(a, launch_seed(sp, n_blocks, s));
   // hit counts -> offsets of each read's slice (also the Mem offsets of thm_smems_batch)
   HIPCHK(a, launch_exclusive_scan_u64(a->s_hits.as<uint64_t>(), a->s_cand_off.as<uint64_t>(), n,
                                       a->scan_tmp.as<uint64_t>(), s));
   return THM_OK;
 }
 
+int enqueue_seed(thm_aligner* a, uint32_t min_seed_len) {
+  return a->dix->wide ? enqueue_seed_t<uint64_t>(a, min_seed_len) : enqueue_seed_t<uint32_t>(a, min_seed_len);
+}
+
+// Length classes of the extend stage for the current options.  Band and buffer sizes grow with the read
+// length, so each class is a range of lengths:
+//   fast   L <= fast_max: band within +-127 and the wave-private buffers within LDS -> register-resident kernel;
+//   slow   fast_max < L <= slow_max: any-width kernel (band in tiles, buffers in global memory);
+//   beyond slow_max: the DP trace alone would exceed the memory budget -> per-read THM_ERR_UNSUPPORTED.
+struct ExtClasses {
+  uint32_t fast_max = 0, fast_len = 0, fast_bw = 0;  // threshold; longest fast read present and its band
+  uint32_t slow_max = 0, slow_len = 0, slow_bw = 0;
+  uint64_t n_slow = 0;
+};
+ExtClasses classify(const thm_aligner* a, uint32_t mk_cap_slow) {
+  ExtClasses c;
+  bool fast_open = true;
+  for (const auto& lc : a->len_hist) {
+    const uint32_t L = lc.first;
+    const uint32_t bw = (uint32_t)band_for_len(a->opts, L);
+    const int cpl = (int)((2 * bw + 1 + 63) / 64);
+    if (fast_open && cpl <= 4 && extend_lds_bytes(L, bw, cpl) <= EXTEND_LDS_LIMIT) {
+      c.fast_len = L;
+      c.fast_bw = bw;
+      continue;
+    }
+    fast_open = false;
+    if (extend_slow_scratch_bytes(L, bw, mk_cap_slow) > SLOW_SCRATCH_BUDGET) break;
+    c.slow_len = L;
+    c.slow_bw = bw;
+    c.n_slow += lc.second;
+  }
+  c.fast_max = c.fast_len;
+  c.slow_max = std::max(c.slow_len, c.fast_len);
+  return c;
+}
+
+template <class C>
+int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow, bool retry_possible) {
+  const uint64_t n = a->n_reads;
+  hipStream_t s = a->stream;
+  ExtendParamsT<C> ep;
+  ep.ix = dev_view<C>(a);
+  ep.reads.bases = a->r_san.as<uint8_t>();
+  ep.reads.offsets = a->r_offsets.as<uint64_t>();
+  ep.reads.n_reads = n;
+  ep.opts = a->opts;
+  ep.smems = a->s_smems.as<SmemT<C>>();
+  ep.read_smem_off = a->s_off.as<uint64_t>();
+  ep.read_smem_cnt = a->s_cnt.as<uint32_t>();
+  ep.read_cand_off = a->s_cand_off.as<uint64_t>();
+  ep.heavy = a->s_heavy.as<unsigned long long>();
+  ep.heavy_count = a->s_work_counts.as<unsigned long long>() + 2;
+  ep.cands = a->e_cands.as<Cand>();
+  ep.cand_cap = a->cand_cap;
+  ep.order = a->e_order.as<uint32_t>();
+  ep.cand_ops = a->e_ops.as<uint8_t>();
+  ep.cand_ops_cap = a->cand_ops_cap;
+  ep.ops_cursor = a->d_cursors.as<unsigned long long>() + 1;
+  ep.read_n_alns = a->e_nalns.as<uint32_t>();
+  ep.read_op_bytes = a->e_opbytes.as<uint64_t>();
+  ep.read_status = a->r_status.as<int32_t>();
+  ep.retry = a->s_slow.as<unsigned long long>();
+  ep.retry_count = a->s_work_counts.as<unsigned long long>() + 5;
+  ep.n_contract = a->s_work_counts.as<unsigned long long>() + 6;
+  ep.counters = a->d_counters.as<unsigned long long>();
+  ep.queue = a->d_queue.as<unsigned int>();
+  ep.fault = a->d_fault.as<int>() + 1;
+  ep.fault_seed = a->d_fault.as<int>();
+  ep.prof = a->d_counters.as<unsigned long long>() + 2 * THM_N_COUNTERS;
+  ep.slow_scratch = nullptr;
+  ep.slow_scratch_per_wave = 0;
+  ep.trace_scratch = nullptr;
+  // ---- fast class ----
+  ep.max_read_len = cls.fast_len;
+  ep.max_bw = cls.fast_bw;
+  ep.mk_cap = FAST_MAX_YCLIPS;
+  ep.list_only = 0;
+  const int cpl = std::max(1, (int)((2 * cls.fast_bw + 1 + 63) / 64));
+  const size_t lds = extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl);
+  const int ext_blocks = blocks_for(a, n, lds);
+  HIPCHK(a, a->e_trace.ensure((size_t)ext_blocks * 4 * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
+  ep.trace_scratch = a->e_trace.as<unsigned long long>();
+  HIPCHK(a, launch_extend(ep, cpl, ext_blocks, s));
+  // ---- slow class (and the fast kernel's retries) ----
+  if (cls.n_slow || retry_possible) {
+    const uint32_t sl_len = std::max(cls.slow_len, cls.fast_len), sl_bw = std::max(cls.slow_bw, cls.fast_bw);
+    const uint64_t per_wave = (extend_slow_scratch_bytes(sl_len, sl_bw, mk_cap_slow) + 255) & ~255ull;
+    uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(SLOW_SCRATCH_BUDGET / std::max<uint64_t>(per_wave, 1), (uint64_t)a->n_cu * 8));
+    if (!retry_possible) waves = std::min(waves, std::max<uint64_t>(cls.n_slow, 1));
+    const int blocks = (int)((waves + 3) / 4);
+    HIPCHK(a, a->e_slow.ensure((size_t)blocks * 4 * per_wave + 256));
+    ep.max_read_len = sl_len;
+    ep.max_bw = sl_bw;
+    ep.mk_cap = mk_cap_slow;
+    ep.list_only = 1;
+    ep.heavy = a->s_slow.as<unsigned long long>();
+    ep.heavy_count = a->s_work_counts.as<unsigned long long>() + 5;
+    ep.slow_scratch = a->e_slow.as<uint8_t>();
+    ep.slow_scratch_per_wave = per_wave;
+    HIPCHK(a, launch_extend(ep, 0, blocks, s));
+  }
+  return THM_OK;
+}
+
 int enqueue_run(thm_aligner* a) {
   const uint64_t n = a->n_reads;
   hipStream_t s = a->stream;
-  const uint32_t bw_max = (uint32_t)band_for_len(a->opts, a->max_read_len);
-  const int cpl = (int)((2 * bw_max + 1 + 63) / 64);
-  if (cpl > 4) return fail(a, THM_ERR_UNSUPPORTED, "band +-%u needs more than 4 cells per lane", bw_max);
-  const size_t lds = extend_lds_bytes(a->max_read_len, bw_max, cpl);
-  if (lds > 64 * 1024)
-    return fail(a, THM_ERR_UNSUPPORTED, "read length %u with band +-%u needs %zu bytes of LDS per workgroup (limit 65536)",
-                a->max_read_len, bw_max, lds);
   // counters as they stood before this attempt, so that a replay after a pool overflow does not count twice
   HIPCHK(a, hipMemcpyAsync(a->d_counters.as<uint8_t>() + THM_N_COUNTERS * 8, a->d_counters.p, THM_N_COUNTERS * 8,
                            hipMemcpyDeviceToDevice, s));
@@ -121,7 +266,8 @@ int enqueue_run(thm_aligner* a) {
   HIPCHK(a, hipEventRecord(a->ev[1], s));
 
   const uint64_t cand_min = a->dbg_cand_cap ? a->dbg_cand_cap : n * 3 + 1024;
-  const uint64_t ops_min = a->dbg_ops_cap ? a->dbg_ops_cap : n * 384 + 65536;
+  // op bytes: about 2 L per exonic alignment (genome + transcript op streams), 384 per read at least
+  const uint64_t ops_min = a->dbg_ops_cap ? a->dbg_ops_cap : std::max<uint64_t>(n * 384, a->n_bases * 3) + 65536;
   if (a->cand_cap < cand_min) a->cand_cap = cand_min;
   if (a->cand_ops_cap < ops_min) a->cand_ops_cap = ops_min;
   HIPCHK(a, a->e_cands.ensure(a->cand_cap * sizeof(Cand)));
@@ -134,40 +280,35 @@ int enqueue_run(thm_aligner* a) {
   HIPCHK(a, a->e_ops_off.ensure((n + 2) * 8));
   HIPCHK(a, a->o_alns.ensure(a->cand_cap * sizeof(thm_aln)));
   HIPCHK(a, a->o_ops.ensure(a->cand_ops_cap + 64));
+  HIPCHK(a, a->s_heavy.ensure((n + 1) * 8));
+  HIPCHK(a, a->s_slow.ensure((n + 1) * 8));
   HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, thm::QUEUE_BYTES, s));
+
+  // length classes for the current options; lists for the extend stage
+  const uint32_t mk_cap_slow = std::max<uint32_t>(a->ix->max_tx_exons, 1);
+  const bool retry_possible = a->ix->max_tx_exons > (uint32_t)FAST_MAX_YCLIPS + 1;
+  const ExtClasses cls = classify(a, mk_cap_slow);
+  a->n_slow_host = cls.n_slow;
+  a->fast_max_len = cls.fast_max;
+  a->slow_max_len = cls.slow_max;
+  PlanParams pp;
+  pp.offsets = a->r_offsets.as<uint64_t>();
+  pp.read_hits = a->s_hits.as<uint64_t>();
+  pp.n_reads = n;
+  pp.fast_max_len = cls.fast_max;
+  pp.slow_max_len = cls.slow_max;
+  pp.heavy = a->s_heavy.as<unsigned long long>();
+  pp.slow = a->s_slow.as<unsigned long long>();
+  pp.counts = a->s_work_counts.as<unsigned long long>();
+  pp.read_status = a->r_status.as<int32_t>();
+  pp.read_n_alns = a->e_nalns.as<uint32_t>();
+  pp.read_op_bytes = a->e_opbytes.as<uint64_t>();
+  HIPCHK(a, launch_plan(pp, s));
   HIPCHK(a, hipEventRecord(a->ev[2], s));
 
-  ExtendParams ep;
-  ep.ix = a->dix->view;
-  ep.reads.bases = a->r_san.as<uint8_t>();
-  ep.reads.offsets = a->r_offsets.as<uint64_t>();
-  ep.reads.n_reads = n;
-  ep.opts = a->opts;
-  ep.smems = a->s_smems.as<Smem>();
-  ep.read_smem_off = a->s_off.as<uint64_t>();
-  ep.read_smem_cnt = a->s_cnt.as<uint32_t>();
-  ep.read_cand_off = a->s_cand_off.as<uint64_t>();
-  ep.heavy = a->s_work_reads.as<unsigned long long>();
-  ep.heavy_count = a->s_work_counts.as<unsigned long long>() + 2;
-  ep.cands = a->e_cands.as<Cand>();
-  ep.cand_cap = a->cand_cap;
-  ep.order = a->e_order.as<uint32_t>();
-  ep.cand_ops = a->e_ops.as<uint8_t>();
-  ep.cand_ops_cap = a->cand_ops_cap;
-  ep.ops_cursor = a->d_cursors.as<unsigned long long>() + 1;
-  ep.read_n_alns = a->e_nalns.as<uint32_t>();
-  ep.read_op_bytes = a->e_opbytes.as<uint64_t>();
-  ep.counters = a->d_counters.as<unsigned long long>();
-  ep.queue = a->d_queue.as<unsigned int>();
-  ep.fault = a->d_fault.as<int>() + 1;
-  ep.fault_seed = a->d_fault.as<int>();
-  ep.max_read_len = a->max_read_len;
-  ep.max_bw = bw_max;
-  ep.prof = a->d_counters.as<unsigned long long>() + 2 * THM_N_COUNTERS;
-  const int ext_blocks = blocks_for(a, n, lds);
-  HIPCHK(a, a->e_trace.ensure((size_t)ext_blocks * 4 * extend_trace_scratch_bytes(a->max_read_len, bw_max, cpl) + 64));
-  ep.trace_scratch = a->e_trace.as<unsigned long long>();
-  HIPCHK(a, launch_extend(ep, cpl, ext_blocks, s));
+  rc = a->dix->wide ? enqueue_extend_t<uint64_t>(a, cls, mk_cap_slow, retry_possible)
+                    : enqueue_extend_t<uint32_t>(a, cls, mk_cap_slow, retry_possible);
+  if (rc != THM_OK) return rc;
   HIPCHK(a, hipEventRecord(a->ev[3], s));
 
   HIPCHK(a, launch_widen_u32_to_u64(a->e_nalns.as<uint32_t>(), a->e_nalns64.as<uint64_t>(), n, s));
@@ -215,6 +356,20 @@ int read_status(thm_aligner* a, RunStatus* st) {
   return THM_OK;
 }
 
+template <class C>
+int expand_mems_t(thm_aligner* a, uint64_t n) {
+  ExpandParamsT<C> xp;
+  xp.ix = dev_view<C>(a);
+  xp.n_reads = n;
+  xp.smems = a->s_smems.as<SmemT<C>>();
+  xp.read_smem_off = a->s_off.as<uint64_t>();
+  xp.read_smem_cnt = a->s_cnt.as<uint32_t>();
+  xp.read_mem_off = a->s_cand_off.as<uint64_t>();
+  xp.mems = a->o_mems.as<thm_mem>();
+  HIPCHK(a, launch_expand(xp, a->stream));
+  return THM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -224,15 +379,38 @@ int32_t thm_batch_upload(thm_aligner* a, const uint8_t* bases, const uint64_t* o
   HIPCHK(a, hipSetDevice(a->device));
   a->uploaded = a->ran = a->synced = false;
   if (n_reads >= 0xFFFFFFF0ull) return fail(a, THM_ERR_UNSUPPORTED, "more than 2^32-16 reads in one batch");
-  uint32_t lmax = 0;
-  for (uint64_t i = 0; i < n_reads; i++) {
-    if (offsets[i + 1] < offsets[i]) return fail(a, THM_ERR_INVALID_ARG, "read offsets are not monotone");
-    uint64_t L = offsets[i + 1] - offsets[i];
-    if (L > 4000) return fail(a, THM_ERR_UNSUPPORTED, "read %llu is %llu bases long (limit 4000)", (unsigned long long)i,
-                              (unsigned long long)L);
-    lmax = std::max<uint32_t>(lmax, (uint32_t)L);
-  }
   if (offsets[0] != 0) return fail(a, THM_ERR_INVALID_ARG, "offsets[0] must be 0");
+  // the lengths present in the batch (usually one or a handful): histogram by sorting the distinct ones
+  uint32_t lmax = 0;
+  uint64_t n_over = 0;
+  a->len_hist.clear();
+  {
+    std::vector<uint64_t> cnt(1024, 0);
+    std::vector<std::pair<uint32_t, uint64_t>> big;
+    for (uint64_t i = 0; i < n_reads; i++) {
+      if (offsets[i + 1] < offsets[i]) return fail(a, THM_ERR_INVALID_ARG, "read offsets are not monotone");
+      const uint64_t L = offsets[i + 1] - offsets[i];
+      if (L > MAX_READ_LEN) {  // the read gets its own status; the batch goes on
+        n_over++;
+        continue;
+      }
+      if (L < cnt.size())
+        cnt[L]++;
+      else
+        big.emplace_back((uint32_t)L, 1);
+      lmax = std::max<uint32_t>(lmax, (uint32_t)L);
+    }
+    for (uint32_t L = 0; L < cnt.size(); L++)
+      if (cnt[L]) a->len_hist.emplace_back(L, cnt[L]);
+    std::sort(big.begin(), big.end());
+    for (const auto& b : big) {
+      if (!a->len_hist.empty() && a->len_hist.back().first == b.first)
+        a->len_hist.back().second++;
+      else
+        a->len_hist.push_back(b);
+    }
+  }
+  a->n_over = n_over;
   a->n_reads = n_reads;
   a->n_bases = offsets[n_reads];
   a->max_read_len = lmax;
@@ -266,12 +444,7 @@ int32_t thm_batch_sync(thm_aligner* a) {
     int rc = read_status(a, &st);
     if (rc != THM_OK) return rc;
     // a seed-pool overflow comes first: the extend kernel did not run on that attempt (its fault word means nothing)
-    if (!st.fault_seed) {
-      if (st.fault_ext & 2) return fail(a, THM_ERR_INTERNAL, "extend kernel reported an internal inconsistency");
-      if (st.fault_ext & 4)
-        return fail(a, THM_ERR_OUT_OF_CONTRACT,
-                    "a read hit a condition that panics in the reference (lift_mem_to_tx / lift_tx_to_gx)");
-    }
+    if (!st.fault_seed && (st.fault_ext & 2)) return fail(a, THM_ERR_INTERNAL, "extend kernel reported an internal inconsistency");
     const bool grow = st.fault_seed || (st.fault_ext & 1);
     if (!grow) {
       float ms = 0;
@@ -308,10 +481,15 @@ int32_t thm_batch_fetch(thm_aligner* a, thm_batch_view* out) {
   HBuf& h_off = a->r_off[k];
   HBuf& h_alns = a->r_alns[k];
   HBuf& h_ops = a->r_ops[k];
+  HBuf& h_stat = a->r_stat[k];
   HIPCHK(a, h_off.ensure((n + 2) * 8));
   // offsets, and behind them the op-pool size, in one round trip
   HIPCHK(a, hipMemcpyAsync(h_off.p, a->e_aln_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(a, hipMemcpyAsync(h_off.as<uint64_t>() + n + 1, a->e_ops_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+  // per-read statuses travel only when a read can have failed: reads beyond the classes are known to the host,
+  // out-of-contract reads are counted by the device (the word behind the list counters)
+  unsigned long long n_contract = 0;
+  HIPCHK(a, hipMemcpyAsync(&n_contract, a->s_work_counts.as<unsigned long long>() + 6, 8, hipMemcpyDeviceToHost, s));
   HIPCHK(a, hipStreamSynchronize(s));
   const uint64_t n_alns = h_off.as<uint64_t>()[n];
   const uint64_t n_ops = h_off.as<uint64_t>()[n + 1];
@@ -319,6 +497,14 @@ int32_t thm_batch_fetch(thm_aligner* a, thm_batch_view* out) {
   HIPCHK(a, h_ops.ensure(n_ops));
   if (n_alns) HIPCHK(a, hipMemcpyAsync(h_alns.p, a->o_alns.p, n_alns * sizeof(thm_aln), hipMemcpyDeviceToHost, s));
   if (n_ops) HIPCHK(a, hipMemcpyAsync(h_ops.p, a->o_ops.p, n_ops, hipMemcpyDeviceToHost, s));
+  uint64_t n_beyond = a->n_over;
+  for (const auto& lc : a->len_hist)
+    if (lc.first > a->slow_max_len) n_beyond += lc.second;
+  const bool any_failed = n_beyond || n_contract;
+  if (any_failed) {
+    HIPCHK(a, h_stat.ensure((n + 1) * 4));
+    HIPCHK(a, hipMemcpyAsync(h_stat.p, a->r_status.p, n * 4, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(a, hipStreamSynchronize(s));
   out->n_reads = n;
   out->n_alns = n_alns;
@@ -326,6 +512,15 @@ int32_t thm_batch_fetch(thm_aligner* a, thm_batch_view* out) {
   out->read_aln_off = h_off.as<uint64_t>();
   out->alns = h_alns.as<thm_aln>();
   out->ops = h_ops.as<uint8_t>();
+  out->n_failed_reads = 0;
+  out->read_status = nullptr;
+  if (any_failed) {
+    const int32_t* st = h_stat.as<int32_t>();
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; i++) bad += st[i] != THM_OK;
+    out->n_failed_reads = bad;
+    out->read_status = bad ? st : nullptr;
+  }
   return THM_OK;
 }
 
@@ -368,15 +563,8 @@ int32_t thm_smems_batch(thm_aligner* a, const uint8_t* bases, const uint64_t* of
   const uint64_t n_mems = st.total_hits;
   if (n_mems * sizeof(thm_mem) > (64ull << 30)) return fail(a, THM_ERR_OOM, "%llu seed hits in one batch", st.total_hits);
   HIPCHK(a, a->o_mems.ensure(n_mems * sizeof(thm_mem) + 64));
-  ExpandParams xp;
-  xp.ix = a->dix->view;
-  xp.n_reads = n;
-  xp.smems = a->s_smems.as<Smem>();
-  xp.read_smem_off = a->s_off.as<uint64_t>();
-  xp.read_smem_cnt = a->s_cnt.as<uint32_t>();
-  xp.read_mem_off = a->s_cand_off.as<uint64_t>();
-  xp.mems = a->o_mems.as<thm_mem>();
-  HIPCHK(a, launch_expand(xp, s));
+  rc = a->dix->wide ? expand_mems_t<uint64_t>(a, n) : expand_mems_t<uint32_t>(a, n);
+  if (rc != THM_OK) return rc;
   a->h_off.assign(n + 1, 0);
   a->h_mems.resize(n_mems);
   HIPCHK(a, hipMemcpyAsync(a->h_off.data(), a->s_cand_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, s));

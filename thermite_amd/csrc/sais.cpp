@@ -16,39 +16,41 @@
 namespace thm {
 namespace {
 
-template <class CharT>
+// I = index type: int32_t for texts below 2^31 symbols, int64_t above (the reference builds with
+// divsufsort64, src/index.rs:103-105, 364-380)
+template <class CharT, class I>
 struct Sais {
   const CharT* s;
-  int32_t* SA;  // n + 1 entries; SA[0] is the virtual sentinel suffix n
-  int32_t n, K;
+  I* SA;  // n + 1 entries; SA[0] is the virtual sentinel suffix n
+  I n, K;
   std::vector<uint8_t> t;  // 1 = S-type, 0 = L-type; t[n] = S
-  std::vector<int32_t> cnt, bkt;
+  std::vector<I> cnt, bkt;
 
-  inline bool is_lms(int32_t i) const { return i > 0 && t[i] && !t[i - 1]; }
+  inline bool is_lms(I i) const { return i > 0 && t[i] && !t[i - 1]; }
 
   void buckets(bool end) {
-    int32_t sum = 1;  // slot 0 belongs to the sentinel
-    for (int32_t c = 0; c < K; c++) {
+    I sum = 1;  // slot 0 belongs to the sentinel
+    for (I c = 0; c < K; c++) {
       sum += cnt[c];
       bkt[c] = end ? sum : sum - cnt[c];
     }
   }
   void induce() {
     buckets(false);
-    for (int32_t i = 0; i <= n; i++) {
-      int32_t j = SA[i];
+    for (I i = 0; i <= n; i++) {
+      I j = SA[i];
       if (j > 0 && !t[j - 1]) SA[bkt[s[j - 1]]++] = j - 1;
     }
     buckets(true);
-    for (int32_t i = n; i >= 1; i--) {
-      int32_t j = SA[i];
+    for (I i = n; i >= 1; i--) {
+      I j = SA[i];
       if (j > 0 && t[j - 1]) SA[--bkt[s[j - 1]]] = j - 1;
     }
   }
-  bool lms_equal(int32_t a, int32_t b) const {
+  bool lms_equal(I a, I b) const {
     if (a == n || b == n) return false;
-    for (int32_t d = 0;; d++) {
-      int32_t pa = a + d, pb = b + d;
+    for (I d = 0;; d++) {
+      I pa = a + d, pb = b + d;
       if (pa == n || pb == n) return false;
       if (s[pa] != s[pb] || t[pa] != t[pb]) return false;
       if (d > 0) {
@@ -66,17 +68,17 @@ struct Sais {
     t.assign((size_t)n + 1, 0);
     t[n] = 1;
     t[n - 1] = 0;
-    for (int32_t i = n - 2; i >= 0; i--) t[i] = (s[i] < s[i + 1] || (s[i] == s[i + 1] && t[i + 1])) ? 1 : 0;
+    for (I i = n - 2; i >= 0; i--) t[i] = (s[i] < s[i + 1] || (s[i] == s[i + 1] && t[i + 1])) ? 1 : 0;
     cnt.assign(K, 0);
     bkt.assign(K, 0);
-    for (int32_t i = 0; i < n; i++) cnt[s[i]]++;
+    for (I i = 0; i < n; i++) cnt[s[i]]++;
 
     // 1. sort the LMS substrings
-    for (int32_t i = 0; i <= n; i++) SA[i] = -1;
+    for (I i = 0; i <= n; i++) SA[i] = -1;
     SA[0] = n;
     buckets(true);
-    int32_t n1 = 1;
-    for (int32_t i = 1; i < n; i++)
+    I n1 = 1;
+    for (I i = 1; i < n; i++)
       if (is_lms(i)) {
         SA[--bkt[s[i]]] = i;
         n1++;
@@ -84,44 +86,44 @@ struct Sais {
     induce();
 
     // 2. name them
-    std::vector<int32_t> sorted_lms;
+    std::vector<I> sorted_lms;
     sorted_lms.reserve(n1);
-    for (int32_t i = 0; i <= n; i++)
+    for (I i = 0; i <= n; i++)
       if (is_lms(SA[i])) sorted_lms.push_back(SA[i]);
-    std::vector<int32_t> name_at((size_t)n / 2 + 2, -1);
-    int32_t name = 0;
+    std::vector<I> name_at((size_t)n / 2 + 2, -1);
+    I name = 0;
     name_at[sorted_lms[0] >> 1] = 0;
-    for (int32_t r = 1; r < n1; r++) {
+    for (I r = 1; r < n1; r++) {
       if (!lms_equal(sorted_lms[r - 1], sorted_lms[r])) name++;
       name_at[sorted_lms[r] >> 1] = name;
     }
     // reduced string in text order; its last symbol is the sentinel (name 0, unique)
-    std::vector<int32_t> lms_pos;
+    std::vector<I> lms_pos;
     lms_pos.reserve(n1);
-    for (int32_t i = 1; i <= n; i++)
+    for (I i = 1; i <= n; i++)
       if (is_lms(i)) lms_pos.push_back(i);
-    std::vector<int32_t> sa1((size_t)n1);
+    std::vector<I> sa1((size_t)n1);
     if (name + 1 == n1) {
-      for (int32_t k = 0; k < n1; k++) sa1[name_at[lms_pos[k] >> 1]] = k;
+      for (I k = 0; k < n1; k++) sa1[name_at[lms_pos[k] >> 1]] = k;
     } else {
-      std::vector<int32_t> s1((size_t)n1 - 1);
-      for (int32_t k = 0; k + 1 < n1; k++) s1[k] = name_at[lms_pos[k] >> 1] - 1;
-      Sais<int32_t> sub;
+      std::vector<I> s1((size_t)n1 - 1);
+      for (I k = 0; k + 1 < n1; k++) s1[k] = name_at[lms_pos[k] >> 1] - 1;
+      Sais<I, I> sub;
       sub.s = s1.data();
       sub.SA = sa1.data();
       sub.n = n1 - 1;
       sub.K = name;
       sub.run();
     }
-    std::vector<int32_t>().swap(name_at);
-    std::vector<int32_t>().swap(sorted_lms);
+    std::vector<I>().swap(name_at);
+    std::vector<I>().swap(sorted_lms);
 
     // 3. induce the full order from the sorted LMS suffixes
-    for (int32_t i = 0; i <= n; i++) SA[i] = -1;
+    for (I i = 0; i <= n; i++) SA[i] = -1;
     SA[0] = n;
     buckets(true);
-    for (int32_t r = n1 - 1; r >= 1; r--) {
-      int32_t p = lms_pos[sa1[r]];
+    for (I r = n1 - 1; r >= 1; r--) {
+      I p = lms_pos[sa1[r]];
       SA[--bkt[s[p]]] = p;
     }
     induce();
@@ -133,13 +135,27 @@ struct Sais {
 int build_suffix_array(const uint8_t* text, uint64_t n, uint32_t* out) {
   if (n >= 0x7FFFFFF0ull) return -4;
   std::vector<int32_t> sa((size_t)n + 1);
-  Sais<uint8_t> top;
+  Sais<uint8_t, int32_t> top;
   top.s = text;
   top.SA = sa.data();
   top.n = (int32_t)n;
   top.K = 256;
   top.run();
   for (uint64_t i = 0; i < n; i++) out[i] = (uint32_t)sa[i + 1];
+  return 0;
+}
+
+// 64-bit ranks and positions: any text length (memory: 9 bytes per symbol plus the recursion)
+int build_suffix_array64(const uint8_t* text, uint64_t n, uint64_t* out) {
+  if (n >= (1ull << 62)) return -4;
+  std::vector<int64_t> sa((size_t)n + 1);
+  Sais<uint8_t, int64_t> top;
+  top.s = text;
+  top.SA = sa.data();
+  top.n = (int64_t)n;
+  top.K = 256;
+  top.run();
+  for (uint64_t i = 0; i < n; i++) out[i] = (uint64_t)sa[i + 1];
   return 0;
 }
 

@@ -19,11 +19,17 @@
 //     prefix-max of (D'[k] - k*ge), done with 7 DPP steps (row_shr 1/2/4/8,
 //     row_bcast 15/31, wave_shr 1);
 //   * trace directions are 2 bits per cell: two 64-bit ballots per register
-//     slice per column, stored to LDS by one lane (16*CPL bytes per column);
-//   * the running argmax is kept per lane (first strict improvement, like the
-//     reference's scan order) and reduced across lanes once at the end by
-//     (score desc, column asc, row asc);
-//   * traceback walks the LDS trace from the max cell.
+//     slice per column, stored by one lane (16*CPL bytes per column; LDS for the
+//     one-cell-per-lane code, a per-wave scratch in global memory for wider bands);
+//   * no per-lane argmax: every cell derives from the previous column by moves worth
+//     at most +1, so the running maximum (an SGPR) rises by exactly 1 iff some lane
+//     beats it; the first cell attaining the final maximum is the lowest improving
+//     row of the last improving column (one ballot mask kept per improving column);
+//   * traceback keeps the ballot words of 64 columns in registers (lane t <-> column)
+//     and resolves a whole diagonal run per step;
+//   * bands of any width (more than 256 slots: reads of several hundred bases with a
+//     low score threshold) run through swg_extend_tiled below: the band in tiles of
+//     64 slots, the column state in a wave-private array in global memory.
 //
 // Scoring is the aligner's fixed Scoring::from_scores(-1,-1,1,-1)
 // (reference src/aligner.rs:140).
@@ -523,6 +529,223 @@ __device__ int swg_traceback_wave(const unsigned long long* trace, int i, int j,
       continue;
     }
     const int op = __builtin_amdgcn_readlane(dir, t0);
+    if (op <= OPK_SUBST) return -1;  // a diagonal move out of row 0
+    if (n >= max_ops) return -1;
+    if (lane == 0) ops[n * stride] = (uint8_t)op;
+    n++;
+    if (op == OPK_INS) {
+      if (i == 0) return -1;
+      i--;
+    } else {
+      j--;
+    }
+  }
+  return n;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Band of any width (the reference allocates whatever 2*max_band_width+1 asks for, src/swg.rs:17-26):
+// the slots of a column are walked in tiles of 64 (slot b = 64*t + lane); the column state D, C of the
+// previous and the current column lives in four wave-private int arrays of `stride` entries each
+// (dp[0..stride) = D even columns, then C even, D odd, C odd; stride >= 2*bw + 66), the vertical chain
+// is the same exclusive prefix-max with a carry from tile to tile, the trace is two ballots per tile and
+// column at trace[(j * T + t) * 2], T = ceil((2*bw+1) / 64).  Same results as swg_extend_wave: same
+// recurrences, tie rules, X-drop and exact early exit.  This is the slow path: it serves the rare reads
+// whose band exceeds what the register-resident kernels hold, not the benchmark.
+__device__ __forceinline__ void tiled_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+__device__ inline SwgResult swg_extend_tiled(const uint8_t* xs, int dx, int xlen, const uint8_t* ys, int dy, int ylen, int bw, int xd,
+                                             unsigned long long* trace, int* dp, int stride) {
+  SwgResult res;
+  res.score = 0;
+  res.xend = 0;
+  res.yend = 0;
+  res.cells = 0;
+  res.cols = 0;
+  res.jmax = 0;
+  res.broke = (xlen == 0);
+  if (xlen == 0 || ylen == 0) return res;  // reference :39-55
+  const int lane = lane_id();
+  const int w = 2 * bw + 1;
+  const int T = (w + 63) >> 6;
+  constexpr int ge = GAP_EXTEND, go = GAP_OPEN;
+  int* Dbuf[2] = {dp, dp + 2 * (size_t)stride};
+  int* Cbuf[2] = {dp + stride, dp + 3 * (size_t)stride};
+  // reference :62-71 leftmost column (one slot past the band is written too: phase 2 reads slot b + 1)
+  for (int b = lane; b < T * 64 + 1; b += 64) {
+    Dbuf[0][b] = (b == 0) ? 0 : b * ge + go;
+    Cbuf[0][b] = (b == 0) ? 0 : MIN_SCORE;
+    Dbuf[1][b] = MIN_SCORE;
+    Cbuf[1][b] = MIN_SCORE;
+  }
+  tiled_sync();
+  int run_max = 0, best_j = 0, best_b = 0;
+  bool finished = false;
+  int last_j = 0;
+  bool empty_col = false;
+  const int p1_end = min(bw, ylen);
+  const int rows1 = min(w, xlen + 1);
+
+  // one column; returns true when the walk stops after it
+  auto column = [&](int j, bool phase2) -> bool {
+    const int top = phase2 ? j - bw : 0;
+    const int nvalid = phase2 ? min(w, xlen + 1 - top) : rows1;
+    const int tv = (nvalid + 63) >> 6;
+    const int* Dp = Dbuf[(j - 1) & 1];
+    const int* Cp = Cbuf[(j - 1) & 1];
+    int* Dc = Dbuf[j & 1];
+    int* Cc = Cbuf[j & 1];
+    const int yc = (int)ys[(j - 1) * dy];
+    const int xfloor = run_max - xd;
+    const int alive_floor = run_max - xlen + top;
+    int carry = NEG;
+    unsigned long long any_imp = 0, any_x = 0, any_alive = 0;
+    int col_bmin = -1;
+    unsigned long long* tr = trace + (size_t)j * T * 2;
+    for (int t = 0; t < tv; t++) {
+      const int b = t * 64 + lane;
+      const bool valid = b < nvalid;
+      int d, Cn;
+      bool eq;
+      if (!phase2) {
+        // reference :80-98: C and D of the same slot, diagonal from the slot above
+        const int dprev = Dp[b], cprev = Cp[b];
+        const int dabove = (b > 0) ? Dp[b - 1] : MIN_SCORE;
+        Cn = max(cprev, dprev + go) + ge;
+        const int xi = min(max(b - 1, 0), xlen - 1);
+        eq = (int)xs[xi * dx] == yc;
+        d = dabove + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+      } else {
+        // reference :119-140: C from slot b + 1 of the previous column (same row), diagonal from the same slot
+        const int dprev = Dp[b];
+        const int dnext = Dp[b + 1], cnext = Cp[b + 1];
+        Cn = (b >= w - 1) ? MIN_SCORE : max(cnext, dnext + go) + ge;
+        const int xi = min(max(top + b - 1, 0), xlen - 1);
+        eq = (int)xs[xi * dx] == yc;
+        d = dprev + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+      }
+      // slots without a cell (only at the top of the last tile) sit above every slot with one: nothing feeds down from them
+      const int key = max(d, Cn) - b * ge;
+      const int incl = wave_incl_max_scan(key);
+      const int run = max(carry, wave_shr1(incl, NEG));
+      carry = max(carry, __builtin_amdgcn_readlane(incl, 63));
+      const int R = run + (go + b * ge);
+      const int Dn = max(max(d, Cn), R);
+      const unsigned long long vm = vote(valid);
+      // direction bits (Match 0, Subst 1, Del 2, Ins 3; priority diag > Del > Ins, reference :226-240)
+      const unsigned long long hi = vote(Dn != d);
+      const unsigned long long lo = (~hi & ~vote(eq)) | (hi & vote(Dn != Cn));
+      if (lane == 0) {
+        tr[t * 2 + 0] = lo;
+        tr[t * 2 + 1] = hi;
+      }
+      const unsigned long long m_c = vote(Dn > run_max) & vm;
+      if (m_c && col_bmin < 0) col_bmin = t * 64 + (int)__builtin_ctzll(m_c);
+      any_imp |= m_c;
+      any_x |= vote(Dn >= xfloor) & vm;
+      any_alive |= vote(Dn - b > alive_floor) & vm;
+      Dc[b] = Dn;
+      Cc[b] = Cn;
+    }
+    tiled_sync();
+    last_j = j;
+    const bool imp = any_imp != 0ull;
+    if (imp) {
+      best_j = j;
+      best_b = col_bmin;
+      run_max += MATCH_SCORE;
+    }
+    if (!phase2) return any_alive == 0ull;  // reference :110 cannot fire in phase 1 (x_drop >= band_width); the early exit is ours
+    return !imp && (any_x == 0ull || any_alive == 0ull);
+  };
+
+  for (int j = 1; j <= p1_end; j++) {
+    if (column(j, false)) {
+      finished = true;
+      res.broke = true;
+      break;
+    }
+  }
+  if (!finished && bw + 1 <= ylen) {
+    for (int j = bw + 1; j <= ylen; j++) {
+      if (j - bw > xlen) {  // empty row range: band_max = MIN -> X-drop (reference :117-153)
+        res.broke = true;
+        empty_col = true;
+        break;
+      }
+      if (column(j, true)) {
+        res.broke = true;
+        break;
+      }
+    }
+  }
+  // counters (same closed form as swg_extend_wave)
+  {
+    res.jmax = last_j;
+    res.cols = (unsigned)last_j + (empty_col ? 1u : 0u);
+    const int n1 = min(last_j, p1_end);
+    unsigned cells = (unsigned)n1 * (unsigned)rows1;
+    if (last_j > p1_end) {
+      const int t1 = last_j - bw;
+      const int tfull = min(t1, xlen + 1 - w);
+      if (tfull >= 1) cells += (unsigned)tfull * (unsigned)w;
+      const int ta = max(tfull, 0) + 1;
+      if (t1 >= ta) {
+        const int hi_cells = xlen + 1 - ta, lo_cells = xlen + 1 - t1;
+        cells += (unsigned)(((long long)(hi_cells + lo_cells) * (t1 - ta + 1)) / 2);
+      }
+    }
+    res.cells = cells;
+  }
+  if (run_max > 0) {
+    res.score = run_max;
+    res.xend = max(best_j - bw, 0) + best_b;
+    res.yend = best_j;
+  }
+  return res;
+}
+
+// trace() for the tiled layout: every lane tests the cell its diagonal hypothesis lands on (one round trip to
+// the trace per diagonal run); gap steps one at a time.
+__device__ inline int swg_traceback_tiled(const unsigned long long* trace, int i, int j, int bw, uint8_t* ops, int stride, int max_ops) {
+  const int lane = lane_id();
+  i = bcast_first(i);
+  j = bcast_first(j);
+  bw = bcast_first(bw);
+  const int w = 2 * bw + 1;
+  const int T = (w + 63) >> 6;
+  int n = 0;
+  while (i > 0 || j > 0) {
+    if (j == 0) {  // column 0 is all Ins (reference :65,:70)
+      if (n + i > max_ops) return -1;
+#pragma unroll 1
+      for (int s = lane; s < i; s += 64) ops[(n + s) * stride] = (uint8_t)OPK_INS;
+      n += i;
+      break;
+    }
+    const int ii = i - lane, jj = j - lane;
+    const int top = max(jj - bw, 0);
+    const int b = ii - top;
+    const bool cell_ok = (jj >= 1) && (ii >= 0) && (b >= 0) && (b < w);
+    int dir = 0;
+    if (cell_ok) {
+      const unsigned long long* tw = trace + ((size_t)jj * T + (b >> 6)) * 2;
+      dir = (int)((tw[0] >> (b & 63)) & 1ull) | ((int)((tw[1] >> (b & 63)) & 1ull) << 1);
+    }
+    const unsigned long long okm = __ballot(cell_ok);
+    if (!(okm & 1ull)) return -1;
+    const unsigned long long dm = __ballot(cell_ok && ii >= 1 && dir <= OPK_SUBST);
+    const int run = (~dm == 0ull) ? 64 : (int)__builtin_ctzll(~dm);
+    if (run > 0) {
+      if (n + run > max_ops) return -1;
+      if (lane < run) ops[(n + lane) * stride] = (uint8_t)dir;
+      n += run;
+      i -= run;
+      j -= run;
+      continue;
+    }
+    const int op = __builtin_amdgcn_readlane(dir, 0);
     if (op <= OPK_SUBST) return -1;  // a diagonal move out of row 0
     if (n >= max_ops) return -1;
     if (lane == 0) ops[n * stride] = (uint8_t)op;

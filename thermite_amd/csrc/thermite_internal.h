@@ -38,21 +38,33 @@ static_assert(sizeof(TreeNode) == 40, "TreeNode layout");
 // only skips subtrees, it never reorders).  A query reads one or two adjacent
 // bins in two memory round trips instead of walking ~log2(n) dependent nodes.
 constexpr uint32_t GRID_SHIFT = 10;
-struct GridEntry {
-  uint32_t start, end, value;
+
+// Coordinate width.  C = uint32_t: text positions and suffix-array ranks fit 32 bits (text below 2^31
+// symbols; the default: half the index bytes, and wave-uniform coordinate arithmetic stays on the 32-bit
+// scalar unit).  C = uint64_t: any text length -- the reference's usize coordinates (src/index.rs:364-388;
+// a GRCh38-sized text has 6.2 G symbols).  Every structure that holds a text position or a rank is
+// templated on C, and so are the kernels that read them.
+template <class C>
+struct GridEntryT {
+  C start, end;
+  uint32_t value;
   uint32_t rank;  // (pre-order rank << 8) | (bin & 0xff): the low byte tells the copies of one interval apart
 };
+static_assert(sizeof(GridEntryT<uint32_t>) == 16 && sizeof(GridEntryT<uint64_t>) == 24, "GridEntry layout");
 
 // k-mer prefix table entry: suffix-array interval of one ACGT-only kt-mer
-struct LutEntry {
-  uint32_t lo, hi;
+template <class C>
+struct LutEntryT {
+  C lo, hi;
 };
 
 // device-side view of the index (all pointers in HBM)
-struct DeviceIndex {
-  const uint8_t* text;  // n symbols + 16 bytes of '$' padding
-  const uint32_t* sa;   // n
-  const LutEntry* lut;  // 4^kt
+template <class C>
+struct DeviceIndexT {
+  typedef C coord_t;
+  const uint8_t* text;  // n symbols + 128 bytes of '$' padding
+  const C* sa;          // n
+  const LutEntryT<C>* lut;  // 4^kt
   const thm_ref* refs;
   const uint32_t* name_rank;  // per ref
   const thm_tx* txs;
@@ -60,24 +72,27 @@ struct DeviceIndex {
   const uint64_t* exon_txoff;  // per exon: offset of its first base in the transcript
   const uint8_t* tx_seq;
   const uint32_t* exon_grid_off;  // [n_bins + 1]
-  const GridEntry* exon_grid;
+  const GridEntryT<C>* exon_grid;
   const uint32_t* gene_grid_off;
-  const GridEntry* gene_grid;
+  const GridEntryT<C>* gene_grid;
   uint64_t n;
   uint32_t n_refs, n_txs;
   uint32_t kt;
-  uint32_t pad_;
+  uint32_t max_tx_exons;  // most exons any transcript has (bounds the introns one alignment can span)
 };
 
 // one SMEM as the seed kernel emits it: occurrences are sa[lo..hi)
-struct Smem {
-  uint32_t lo, hi;
+template <class C>
+struct SmemT {
+  C lo, hi;
   uint16_t qpos, len;
 };
-static_assert(sizeof(Smem) == 12, "Smem layout");
+static_assert(sizeof(SmemT<uint32_t>) == 12 && sizeof(SmemT<uint64_t>) == 24, "Smem layout");
 
 int build_suffix_array(const uint8_t* text, uint64_t n, uint32_t* out);
-bool verify_suffix_array(const uint8_t* text, uint64_t n, const uint32_t* sa);
+int build_suffix_array64(const uint8_t* text, uint64_t n, uint64_t* out);
+template <class C>
+bool verify_suffix_array(const uint8_t* text, uint64_t n, const C* sa);
 
 void set_global_error(const std::string& msg);
 
@@ -86,9 +101,14 @@ void set_global_error(const std::string& msg);
 // Host index: owns the tables; device copies are created lazily per device.
 struct thm_index {
   std::vector<uint8_t> text;
+  // exactly one of the two coordinate widths is populated (thermite_internal.h, "Coordinate width")
+  bool wide = false;
   std::vector<uint32_t> sa;
-  std::vector<thm::LutEntry> lut;
+  std::vector<uint64_t> sa64;
+  std::vector<thm::LutEntryT<uint32_t>> lut;
+  std::vector<thm::LutEntryT<uint64_t>> lut64;
   uint32_t kt = 0;
+  uint32_t max_tx_exons = 0;
   std::vector<thm_ref> refs;
   std::vector<uint32_t> name_rank;  // per ref
   std::vector<thm_tx> txs;
@@ -99,7 +119,8 @@ struct thm_index {
   std::vector<thm::TreeNode> exon_tree, gene_tree;
   int32_t exon_root = -1, gene_root = -1;
   std::vector<uint32_t> exon_grid_off, gene_grid_off;
-  std::vector<thm::GridEntry> exon_grid, gene_grid;
+  std::vector<thm::GridEntryT<uint32_t>> exon_grid, gene_grid;
+  std::vector<thm::GridEntryT<uint64_t>> exon_grid64, gene_grid64;
   uint64_t n = 0;
   // names for the writer (Ref::name, Tx::id, Gene::{id,name}); empty when not supplied
   std::vector<std::string> contig_names, tx_ids, gene_ids, gene_names;
