@@ -2,27 +2,39 @@
 """bench.py -- headline measurement of the seed-and-extend hot path on MI355X.
 
 Metric (BASELINE.json): aligned reads/sec for synthetic 91 bp reads.  One "step"
-= one pass of the hot path (seed kernel -> scan -> extend kernel -> compaction)
-over one batch of reads that is already resident in HBM.  Workload at every N:
-`--reads-per-gpu` (default 500 000, BASELINE configs[2]/[3]) synthetic 91 bp
-reads per GPU against a chr21-sized synthetic reference (46 709 983 bp; the real
-chr21 FASTA/GTF and pbmc10k reads are missing blobs in the reference checkout),
-aligned with the flags the reference uses for its chr21 run,
-`-k20 -s0 --intron-mode` (reference data/Makefile:39).  Reads shard
-embarrassingly: each rank aligns its own reads against its own copy of the
-index; the only collective is one all-reduce (RCCL) of the counter vector.
+= one pass of the hot path (seed kernels -> plan -> scan -> extend kernel ->
+compaction) over one batch of reads that is already resident in HBM.
+
+Workloads
+  N = 1 (default)   BASELINE configs[2]: 500 000 synthetic 91 bp reads per batch against a
+                    chr21-sized synthetic reference (46 709 983 bp; the real chr21 FASTA/GTF and
+                    the pbmc10k reads are missing blobs in the reference checkout), flags of the
+                    reference's chr21 run `-k20 -s0 --intron-mode` (reference data/Makefile:39).
+                    The timed steps rotate over 4 DISTINCT resident batches (4 aligners on the
+                    shared index), so no step replays the batch the caches have just seen.
+  N > 1 (default)   BASELINE configs[3]: ONE seeded stream of 50 000 000 such reads cut into
+                    contiguous shards with thermite_amd.sharding.shard_bounds (6.25 M reads per GPU
+                    at N = 8; concatenating the shards restores input order, reference
+                    src/aligner.rs:54-115); every rank generates only its own shard.  Index
+                    replicated per GPU; the only collective is one all-reduce (RCCL) of the
+                    counter vector.  "scaling": "strong" (the total is fixed).
+  --reads-per-gpu R weak scaling instead: R reads per rank, each rank its own stream.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     -- extend kernel: algorithmic bytes per launch / mean launch time
-                  (HIP events on the aligner's stream, inside the timed region)
-  cpu_baseline -- the CPU oracle (a port of the reference algorithm; the Rust
-                  reference cannot be built here) timed on a bounded sample of
-                  the same reads on this box's host cores.
+  roofline      -- extend kernel: algorithmic bytes per launch / mean launch time (HIP events on the
+                   aligner's stream, inside the timed region), HBM traffic from the committed PMC profile;
+  roofline_valu -- the resource that actually binds the kernel: vector-ALU issue (SQ counters from the
+                   committed profile) and DP cells / s (live);
+  value_e2e     -- reads/s including host<->device transfers (upload + run + fetch of distinct batches,
+                   two aligners on two host threads so that transfers overlap kernels); never `value`;
+  cpu_baseline  -- the CPU oracle (a port of the reference algorithm; the Rust reference cannot be
+                   built here) timed on a bounded sample of the same reads on this box's host cores.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -32,6 +44,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CONFIG4_TOTAL_READS = 50_000_000
+STREAM_CHUNK = 250_000  # reads per chunk of the global seeded stream (chunk c = simulate_reads(stream=1000 + c))
 
 
 def log(rank, *a):
@@ -52,12 +66,42 @@ def load_suffix_array(capi, tables, rank, world, dist, tag):
     return np.load(path, mmap_mode="r")
 
 
+def stream_reads(synth, tables, begin, end, L):
+    """Reads [begin, end) of the global seeded stream, generated chunk by chunk (only the chunks the range touches)."""
+    parts = []
+    c = begin // STREAM_CHUNK
+    while c * STREAM_CHUNK < end:
+        b, _, _ = synth.simulate_reads(tables, STREAM_CHUNK, L, sub_rate=0.01, indel_rate=0.001, stream=1000 + c)
+        lo = max(begin, c * STREAM_CHUNK) - c * STREAM_CHUNK
+        hi = min(end, (c + 1) * STREAM_CHUNK) - c * STREAM_CHUNK
+        parts.append(b[lo * L: hi * L])
+        c += 1
+    bases = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    n = end - begin
+    return bases, (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)).astype("<u8")
+
+
+def profile_entry(name, match):
+    """a committed profile summary (profiles/*.json) if it was taken on this workload, else None"""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        j = json.load(open(path))
+    except Exception:
+        return None
+    return j if all(j.get(k) == v for k, v in match.items()) else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads-per-gpu", type=int, default=500000)
+    ap.add_argument("--reads-per-gpu", type=int, default=None, help="weak scaling: this many reads per rank (default at N = 1: 500 000)")
+    ap.add_argument("--total-reads", type=int, default=None, help="strong scaling: one stream of this many reads sharded over the ranks "
+                                                                    "(default at N > 1: 50 000 000, BASELINE configs[3])")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the timed steps rotate over (weak mode)")
     ap.add_argument("--read-len", type=int, default=91)
     ap.add_argument("--ref-len", type=int, default=int(os.environ.get("THM_BENCH_REF_LEN", "0")) or None)
     ap.add_argument("--opts", choices=["ci", "default"], default="ci")
@@ -65,7 +109,9 @@ def main():
                     help="chr21syn: the headline workload (BASELINE configs[2]); chrM: configs[1], the real chrM FASTA/GTF "
                          "that ship with the reference's data/ (copied to tests/golden/data)")
     ap.add_argument("--percent", type=float, default=None, help="override min_aln_score_percent (config 5: 0.574 at 150 bp = band +-64)")
+    ap.add_argument("--wide", action="store_true", help="64-bit text coordinates inside the index (the path a GRCh38-sized text takes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -87,9 +133,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from thermite_amd import capi, synth
+    from thermite_amd import capi, sharding, synth
 
-    # ---------------- workload ----------------
+    # ---------------- reference + index ----------------
     t0 = time.time()
     if args.workload == "chrM":
         from thermite_amd import refdata
@@ -103,37 +149,59 @@ def main():
         tables = synth.synth_reference(length=ref_len)
         tag = "%d_%x" % (ref_len, synth.SEED)
     sa = load_suffix_array(capi, tables, rank, world, dist, tag)
-    index = capi.Index(tables, sa=sa)
-    log(rank, "reference: %s %d bp, text n=%d, %d transcripts, %d exons; index in %.1fs" % (
-        args.workload, ref_len, len(tables["text"]), len(tables["txs"]), len(tables["exons"]), time.time() - t0))
+    index = capi.Index(tables, sa=sa, wide=args.wide)
+    log(rank, "reference: %s %d bp, text n=%d, %d transcripts, %d exons; index (%d-byte coordinates) in %.1fs" % (
+        args.workload, ref_len, len(tables["text"]), len(tables["txs"]), len(tables["exons"]), index.coord_bytes, time.time() - t0))
     opts = dict(capi.CI_OPTS if args.opts == "ci" else capi.DEFAULT_OPTS)
     if args.percent is not None:
         opts["min_aln_score_percent"] = args.percent
     L = args.read_len
-    bases, offsets, _ = synth.simulate_reads(tables, args.reads_per_gpu, L, sub_rate=0.01, indel_rate=0.001,
-                                             stream=100 + rank)
-    aligner = capi.Aligner(index, opts, device=local_rank)
-    aligner.upload(bases, offsets)  # inputs resident in HBM before the timed region
 
-    # ---------------- warmup (also sizes the device pools) ----------------
-    for _ in range(max(args.warmup, 1)):
-        aligner.run()
-        aligner.sync()
-    aligner.reset_counters()
+    # ---------------- reads: this rank's batches ----------------
+    t0 = time.time()
+    strong = args.reads_per_gpu is None and (args.total_reads is not None or world > 1)
+    if strong:
+        total = args.total_reads or CONFIG4_TOTAL_READS
+        b, e = sharding.shard_bounds(total, rank, world)
+        batches = [stream_reads(synth, tables, b, e, L)]
+        reads_this_rank = e - b
+        desc_reads = "%d synthetic %d bp reads (one seeded stream) in %d contiguous shard(s)" % (total, L, world)
+    else:
+        per = args.reads_per_gpu or 500000
+        nb = max(1, args.batches)
+        batches = [synth.simulate_reads(tables, per, L, sub_rate=0.01, indel_rate=0.001, stream=100 + 16 * rank + k)[:2] for k in range(nb)]
+        reads_this_rank = per
+        desc_reads = "%d synthetic %d bp reads per GPU per step, %d distinct resident batches in rotation" % (per, L, nb)
+    NB = len(batches)
+    log(rank, "reads: %s; rank 0 holds %d x %d reads (generated in %.1fs)" % (desc_reads, NB, reads_this_rank, time.time() - t0))
+    aligners = [capi.Aligner(index, opts, device=local_rank) for _ in range(NB)]
+    for a, (bases, offsets) in zip(aligners, batches):
+        a.upload(bases, offsets)  # inputs resident in HBM before the timed region
+        a.run()                   # sizes the device pools (replays on overflow), untimed
+        a.sync()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---------------- warmup ----------------
+    for i in range(args.warmup):
+        aligners[i % NB].run()
+        aligners[i % NB].sync()
+    for a in aligners:
+        a.reset_counters()
+
     # ---------------- timed region: exactly K steps ----------------
+    K = args.steps
     stage_ms = {k: 0.0 for k in capi.TIMING_NAMES}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        aligner.run()
-        aligner.sync()  # stream sync + pool-overflow check; HIP-event stage times of this launch
-        for k, v in aligner.timings().items():
+    for i in range(K):
+        a = aligners[i % NB]
+        a.run()
+        a.sync()  # stream sync + pool-overflow check; HIP-event stage times of this launch
+        for k, v in a.timings().items():
             stage_ms[k] += v
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -144,15 +212,19 @@ def main():
         elapsed = float(tmax.item())
 
     # ---------------- the one collective: counter all-reduce ----------------
-    cnt_local = aligner.counters()
+    cnt_local = np.zeros(capi.N_COUNTERS, np.uint64)
+    for a in aligners:
+        cnt_local += a.counters()
     cnt = torch.from_numpy(cnt_local.astype(np.int64)).to(dev)
     if world > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     cnt = cnt.cpu().numpy().astype(np.uint64)
     c = dict(zip(capi.COUNTER_NAMES, [int(v) for v in cnt]))
 
-    K = args.steps
-    total_reads = args.reads_per_gpu * world * K
+    if strong:
+        total_reads = (args.total_reads or CONFIG4_TOTAL_READS) * K
+    else:
+        total_reads = reads_this_rank * world * K
     assert c["reads"] == total_reads, (c["reads"], total_reads)
     value = total_reads / elapsed
 
@@ -160,46 +232,82 @@ def main():
     k_seed = int(opts["min_seed_len"])
     lc = dict(zip(capi.COUNTER_NAMES, [int(v) for v in cnt_local]))  # this rank's launches
     per_launch = lambda name: lc[name] / K
-    n_r = args.reads_per_gpu
+    n_r = reads_this_rank
     ext_bytes = (n_r * L + 12 * per_launch("smems") + 4 * per_launch("hits") + per_launch("window_bytes")
                  + 112 * per_launch("alns") + per_launch("op_bytes"))
     seed_bytes = n_r * L + n_r * max(L - k_seed + 1, 0) * 16 + 12 * per_launch("smems")
     ext_ms = stage_ms["extend"] / K
     achieved = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if (tj.get("reads_per_gpu") == n_r and tj.get("ref_len") == ref_len and tj.get("opts") == args.opts
-                    and args.workload == "chr21syn" and args.percent is None and L == 91):
-                traffic = tj.get("extend_kernel_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    headline = (not strong and n_r == 500000 and args.workload == "chr21syn" and args.percent is None and L == 91
+                and not args.wide and ref_len == synth.CHR21_LEN)
+    match = {"reads_per_gpu": n_r, "ref_len": ref_len, "opts": args.opts} if headline else {"reads_per_gpu": -1}
+    tj = profile_entry("pmc_traffic.json", match)
+    sq = profile_entry("sq_counters.json", match)
     roofline = {
         "kernel": "extend_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": tj.get("extend_kernel_hbm_bytes_per_launch") if tj else None,
         "algorithmic_bytes_per_launch": int(ext_bytes), "kernel_ms": round(ext_ms, 4),
         "algorithmic_bytes_per_read_whole_path": round((ext_bytes + seed_bytes - n_r * L) / n_r, 1),
         "stage_ms": {k: round(v / K, 4) for k, v in stage_ms.items()},
-        "note": "integer DP + random index probes: bound by HBM latency / VALU, not HBM bandwidth (SURVEY.md F7)",
+        "note": "integer DP + random index probes: bound by HBM latency / VALU issue, not HBM bandwidth (SURVEY.md F7); see roofline_valu",
     }
+    # the binding resource: vector-ALU issue.  busy = SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CU_CYCLES-equivalent from the committed
+    # SQ-counter profile of this workload (profiles/sq_counters.json); DP cells per second measured here.
+    roofline_valu = {
+        "kernel": "extend_kernel", "bound": "valu-issue",
+        "dp_cells_per_s": round(per_launch("dp_cells") / (ext_ms * 1e-3), 1) if ext_ms > 0 else None,
+        "dp_cells_per_read": round(per_launch("dp_cells") / max(n_r, 1), 1),
+        "dp_cols_per_read": round(per_launch("dp_cols") / max(n_r, 1), 2),
+        "valu_busy_frac": sq.get("extend_valu_busy_frac") if sq else None,
+        "valu_insts_per_read": sq.get("extend_valu_insts_per_read") if sq else None,
+        "source": sq.get("source") if sq else None,
+    }
+
+    # ---------------- PCIe-inclusive rate (not `value`): upload + run + fetch of distinct batches ----------------
+    value_e2e = None
+    if not args.no_e2e and not strong and NB >= 2:
+        n_thr = 2
+        per_thread = max(2, K // 2)
+
+        def worker(t):
+            a = aligners[t]
+            for j in range(per_thread):
+                bases, offsets = batches[(t + n_thr * j) % NB]
+                a.align_batch(bases, offsets)  # H2D of the reads, kernels, D2H of alignments + op streams
+
+        barrier()
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            tm = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt = float(tm.item())
+        value_e2e = {"value": round(n_thr * per_thread * reads_this_rank * world / dt, 1), "unit": "reads/s",
+                     "what": "host buffers in, host views out: H2D reads + all kernels + D2H alignments and op streams, "
+                             "%d batches on %d aligners / host threads per GPU (transfers overlap kernels)" % (n_thr * per_thread, n_thr)}
 
     # ---------------- CPU baseline (rank 0, N = 1 only) ----------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as orc
 
+        bases, offsets = batches[0]
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         cores = min(cores, 16)  # a one-GPU box owns a 16-thread share of the host
         t1 = time.time()
         oix = orc.Index(tables, sa=sa)
         log(rank, "oracle index (BWT/Occ/sampled SA) in %.1fs; timing on %d host threads" % (time.time() - t1, cores))
-        probe = min(2000 * cores, args.reads_per_gpu)
+        probe = min(2000 * cores, reads_this_rank)
         t1 = time.perf_counter()
         oix.align_batch(bases[: probe * L], offsets[: probe + 1], opts, n_threads=cores)
         rate = probe / (time.perf_counter() - t1)
-        sample = int(min(args.reads_per_gpu, max(probe, rate * args.cpu_seconds)))
+        sample = int(min(reads_this_rank, max(probe, rate * args.cpu_seconds)))
         t1 = time.perf_counter()
         r = oix.align_batch(bases[: sample * L], offsets[: sample + 1], opts, n_threads=cores)
         dt = time.perf_counter() - t1
@@ -209,34 +317,37 @@ def main():
         dt1 = time.perf_counter() - t1
         cpu_baseline = {
             "value": round(sample / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d of the %d reads of rank 0's batch, %.1f s, %d threads" % (sample, args.reads_per_gpu, dt, cores),
+            "sample": "first %d of the %d reads of rank 0's first batch, %.1f s, %d threads" % (sample, reads_this_rank, dt, cores),
             "value_1thread": round(n1 / dt1, 1),
             "note": "CPU restatement of the reference algorithm (oracle/), not the reference Rust binary",
             "aligned_frac": round(float(r.counters[1]) / max(int(r.counters[0]), 1), 4),
         }
 
     if rank == 0:
+        refdesc = "chr21-sized synthetic transcriptome" if args.workload == "chr21syn" else "GRCh38-2020-A chrM (real FASTA/GTF)"
         out = {
             "metric": "aligned reads/sec (%d bp)" % L, "value": round(value, 1), "unit": "reads/s", "n_gpus": world,
             "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {
-                "workload": "%d synthetic %d bp reads per GPU vs %s (%d bp, %d tx), flags %s%s" % (
-                    args.reads_per_gpu, L,
-                    "chr21-sized synthetic transcriptome" if args.workload == "chr21syn" else "GRCh38-2020-A chrM (real FASTA/GTF)",
-                    ref_len, len(tables["txs"]),
+                "workload": "%s vs %s (%d bp, %d tx), flags %s%s" % (
+                    desc_reads, refdesc, ref_len, len(tables["txs"]),
                     "-k20 -s0 --intron-mode" if args.opts == "ci" else "defaults (-k20 -s0.66)",
                     "" if args.percent is None else " with -s%g" % args.percent),
-                "reads_per_gpu": args.reads_per_gpu, "read_len": L, "ref_len": ref_len, "opts": args.opts,
+                "reads_per_gpu_per_step": reads_this_rank, "read_len": L, "ref_len": ref_len, "opts": args.opts,
+                "coord_bytes": index.coord_bytes,
                 "parallelism": "reads sharded over %d GPU(s), index replicated, 1 counter all-reduce" % world,
             },
             "roofline": roofline,
+            "roofline_valu": roofline_valu,
+            "value_e2e": value_e2e,
             "cpu_baseline": cpu_baseline,
             "counters": {k: c[k] for k in ("reads", "aligned", "unmapped", "alns", "exonic", "intronic", "intergenic",
                                            "smems", "hits", "swg_calls", "dp_cells")},
         }
         print(json.dumps(out), flush=True)
-    aligner.close()
+    for a in aligners:
+        a.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

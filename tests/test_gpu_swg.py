@@ -95,6 +95,53 @@ def test_fuzz_any_band_width(aligner, bw_lo, bw_hi, max_len, n):
     assert_swg_equal(alns, ops, ref)
 
 
+def test_one_mismatch_then_exact_shortcut(aligner):
+    """extensions of the shape 'the seed ended on a substitution, the rest matches' take a shortcut without DP
+    (swg_device.h: swg_one_mismatch_shortcut); adversarial inputs around its conditions: short x, one repeated
+    base, two-letter repeats, y ending exactly at |x|, y continuing the repeat, narrow bands, x_drop 0 / 1"""
+    rng = np.random.default_rng(99)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    xs, ys, bws, xds = [], [], [], []
+    for _ in range(6000):
+        xl = int(rng.integers(1, 70))
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            x = acgt[rng.integers(0, 4, xl)]
+        elif kind == 1:
+            x = np.full(xl, acgt[rng.integers(0, 4)], np.uint8)  # one repeated base
+        elif kind == 2:
+            x = np.full(xl, acgt[rng.integers(0, 4)], np.uint8)  # one repeated base except one position
+            x[int(rng.integers(0, xl))] = acgt[rng.integers(0, 4)]
+        elif kind == 3:
+            x = np.tile(acgt[rng.integers(0, 4, 2)], xl)[:xl]  # two-letter repeat
+        else:
+            x = np.tile(acgt[rng.integers(0, 4, int(rng.integers(1, 5)))], xl)[:xl]
+        y = x.copy()
+        if rng.random() < 0.9:
+            y[0] = acgt[(int(np.searchsorted(acgt, y[0])) + int(rng.integers(1, 4))) % 4]  # substitution at the seed's end
+        if rng.random() < 0.15 and xl > 3:
+            y[int(rng.integers(1, xl))] = acgt[rng.integers(0, 4)]  # sometimes a second difference: no shortcut
+        t = rng.integers(0, 4)
+        if t == 1:
+            y = np.concatenate([y, [x[-1]]])  # continues the last base
+        elif t == 2:
+            y = np.concatenate([y, np.full(int(rng.integers(1, 6)), x[0], np.uint8)])
+        elif t == 3:
+            y = np.concatenate([y, acgt[rng.integers(0, 4, int(rng.integers(1, 30)))]])
+        if rng.random() < 0.05:
+            y = y[: int(rng.integers(0, len(y) + 1))]
+        bw = int(rng.choice([0, 1, 2, 3, 5, 31, 61]))
+        xs.append(x)
+        ys.append(y.astype(np.uint8))
+        bws.append(bw)
+        xds.append(bw + int(rng.choice([0, 0, 1, 7])))
+    xb, xo = refdata.pack_reads(xs)
+    yb, yo = refdata.pack_reads(ys)
+    alns, ops = aligner.swg_extend_batch(xb, xo, yb, yo, bws, xds, 61)
+    ref = orc.swg_extend_batch(xb, xo, yb, yo, np.array(bws, "<u4"), np.array(xds, "<i4"), 61)
+    assert_swg_equal(alns, ops, ref)
+
+
 def test_empty_inputs(aligner):
     xs = [b"", b"ACG", b"", b"A"]
     ys = [b"ACGT", b"", b"", b"A"]

@@ -82,3 +82,27 @@ def test_two_rank_gloo_counters_and_order():
     for f in ("score", "ystart", "yend", "ref_id", "aln_type", "ops_len"):
         assert np.array_equal(np.concatenate([g[1][f] for g in gathered]), whole.alns[f])
     assert np.array_equal(np.concatenate([g[2] for g in gathered]), whole.ops)
+
+
+def test_config4_stream_is_cut_into_contiguous_shards():
+    """bench.py's N > 1 workload (BASELINE configs[3]): one seeded stream, each rank generates only its own
+    contiguous shard; the shards concatenate to the stream whatever the world size"""
+    import bench
+
+    t = refdata.load_reference(DATA + "/GRCh38-2020-A-chrM.fasta", DATA + "/GRCh38-2020-A-chrM.gtf")
+    old = bench.STREAM_CHUNK
+    bench.STREAM_CHUNK = 700  # several chunks per shard, shard bounds inside chunks
+    try:
+        total = 5000
+        whole, off = bench.stream_reads(synth, t, 0, total, 91)
+        assert len(whole) == total * 91 and off[-1] == total * 91
+        for world in (2, 3, 8):
+            parts = []
+            for rank in range(world):
+                b, e = sharding.shard_bounds(total, rank, world)
+                pb, po = bench.stream_reads(synth, t, b, e, 91)
+                assert len(po) == e - b + 1
+                parts.append(pb)
+            assert np.array_equal(np.concatenate(parts), whole)
+    finally:
+        bench.STREAM_CHUNK = old

@@ -225,6 +225,9 @@ def lib():
     if hasattr(L, "thm_debug_set_pool_caps"):
         L.thm_debug_set_pool_caps.restype = i32
         L.thm_debug_set_pool_caps.argtypes = [vp, u64, u64, u64, vp]
+    if hasattr(L, "thm_debug_calib_gather"):
+        L.thm_debug_calib_gather.restype = i32
+        L.thm_debug_calib_gather.argtypes = [vp, i32, u64, vp]
     if hasattr(L, "thm_debug_wave_prims"):
         L.thm_debug_wave_prims.restype = i32
         L.thm_debug_wave_prims.argtypes = [vp, vp, vp]
@@ -523,6 +526,12 @@ class Aligner:
         n = C.c_uint32()
         self._chk(lib().thm_debug_set_pool_caps(self.h, smem_cap, cand_cap, ops_cap, C.byref(n)))
         return n.value
+
+    def debug_calib_gather(self, pattern, n_threads):
+        """profiling hook: a gather of known size (see tools/calib_fetch.py); returns the bytes requested"""
+        b = C.c_uint64()
+        self._chk(lib().thm_debug_calib_gather(self.h, pattern, n_threads, C.byref(b)))
+        return b.value
 
     def debug_wave_prims(self, v):
         v = np.ascontiguousarray(v, "<i4")

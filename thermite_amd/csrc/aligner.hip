@@ -369,6 +369,20 @@ int32_t thm_debug_set_pool_caps(thm_aligner* a, uint64_t smem_cap, uint64_t cand
   return THM_OK;
 }
 
+// profiling hook (tools/calib_fetch.py): a gather of known size over the index's k-mer table, in the access patterns of the
+// hot kernels, so that rocprofv3's FETCH_SIZE can be calibrated against a byte count (launch.h: launch_calib_gather).
+// Returns the bytes the lanes ask for through *bytes_requested.
+int32_t thm_debug_calib_gather(thm_aligner* a, int32_t pattern, uint64_t n_threads, uint64_t* bytes_requested) {
+  if (!a || pattern < 0 || pattern > 2) return THM_ERR_INVALID_ARG;
+  HIPCHK(a, hipSetDevice(a->device));
+  const uint64_t span = a->dix->lut.cap & ~255ull;
+  if (span < 4096) return fail(a, THM_ERR_INVALID_ARG, "k-mer table too small for the calibration gather");
+  HIPCHK(a, launch_calib_gather(a->dix->lut.as<uint8_t>(), span, n_threads, pattern, a->d_cursors.as<unsigned long long>() + 4, a->stream));
+  HIPCHK(a, hipStreamSynchronize(a->stream));
+  if (bytes_requested) *bytes_requested = n_threads * (pattern == 0 ? 8 : (pattern == 1 ? 4 : 16));
+  return THM_OK;
+}
+
 // debug hook used by tests/test_gpu_swg.py: wave scan / shift primitives
 int32_t thm_debug_wave_prims(thm_aligner* a, const int32_t in[64], int32_t out[384]) {
   if (!a || !in || !out) return THM_ERR_INVALID_ARG;

@@ -109,7 +109,8 @@ struct WctxT {
 #ifdef THM_PROF
   unsigned long long prof_last;
   unsigned long long prof_acc[10];
-  unsigned long long prof_cols[3];
+  unsigned long long prof_cols[6];
+  int prof_hit, prof_tx;  // index of the hit within its read, 1 while a transcript target is extended
 #endif
 };
 template <class W>
@@ -240,6 +241,13 @@ template <int CPL, class W>
 __device__ __forceinline__ int swg_and_trace(W& c, const uint8_t* xs, int dx, int xlen, const uint8_t* ys, int dy, int ylen,
                                              int bw, int xd, uint8_t* ops, int stride, int max_ops, SwgResult& r) {
   int n;
+#ifndef THM_NO_SHORTCUT
+  if (swg_one_mismatch_shortcut(xs, dx, xlen, ys, dy, ylen, xd, ops, stride, max_ops, r, n)) {
+    wsync(c);
+    PROF_MARK(c, PS_DP);
+    return n;
+  }
+#endif
   if constexpr (CPL == 0) {
     r = swg_extend_tiled(xs, dx, xlen, ys, dy, ylen, bw, xd, c.trace_g, c.dp, c.dp_stride);
     tiled_sync();
@@ -306,6 +314,24 @@ __device__ PathT<S> extend_lr(W& c, const uint8_t* win, S win0, S lo_abs, S hi_a
     c.prof_cols[0] += R.cols + Lt.cols;
     c.prof_cols[1] += (nr_ ? R.cols : 0) + (nl_ ? Lt.cols : 0);
     c.prof_cols[2] += (nr_ && nl_) ? min(R.cols, Lt.cols) : 0;
+    c.prof_cols[3] += (c.prof_hit == 0) ? R.cols + Lt.cols : 0;
+    c.prof_cols[4] += c.prof_tx ? R.cols + Lt.cols : 0;
+    // extensions of the shape "one mismatch, then exact to the end of x" (their result is known without DP)
+    {
+      const uint8_t* yR = win + (int)(r + len - win0);
+      const uint8_t* yL = win + (int)(r - 1 - win0);
+      bool dr = false, dl = false;
+      for (int t0 = 1; t0 < xr; t0 += 64) {
+        const int t = t0 + lane_id();
+        dr = dr || (t < xr && (t >= yr || c.rd[q + len + t] != yR[t]));
+      }
+      for (int t0 = 1; t0 < xl; t0 += 64) {
+        const int t = t0 + lane_id();
+        dl = dl || (t < xl && (t >= yl || c.rd[q - 1 - t] != yL[-t]));
+      }
+      const bool m1r = xr >= 3 && yr >= xr && __ballot(dr) == 0ull, m1l = xl >= 3 && yl >= xl && __ballot(dl) == 0ull;
+      c.prof_cols[5] += (m1r ? R.cols : 0) + (m1l ? Lt.cols : 0);
+    }
   }
 #endif
   if (nr < 0 || nl < 0 || nl + len + nr > c.opcap) {
@@ -625,7 +651,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
   c.pool_left = 0;
 #ifdef THM_PROF
   for (int t = 0; t < 10; t++) c.prof_acc[t] = 0;
-  for (int t = 0; t < 3; t++) c.prof_cols[t] = 0;
+  for (int t = 0; t < 6; t++) c.prof_cols[t] = 0;
+  c.prof_hit = c.prof_tx = 0;
   c.prof_last = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -734,6 +761,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       c.fault |= FAULT_OPS_POOL;
       n_sm = 0;
     }
+#ifdef THM_PROF
+    c.prof_hit = 0;
+#endif
     for (uint32_t si = 0; si < n_sm; si++) {
       const SmemT<C> sm = uload(&p.smems[s0 + si]);
       const int q = sm.qpos, len = sm.len;
@@ -927,6 +957,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
                 PROF_MARK(c, PS_TXPREP);
               }
             }
+#ifdef THM_PROF
+            c.prof_tx = genome_done ? 1 : 0;
+#endif
             if (!reused)
               pth = extend_lr<CPL, S>(c, genome_done ? c.win : c.wing, win0, lo_abs, hi_abs, t_r, t_q, t_len, bw, xd, buf,
                                       genome_done ? tmemo : gmemo);
@@ -1055,6 +1088,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
             x_drop = min(x_drop, lim);
             max_aln_score = max(max_aln_score, sc);
           }
+#ifdef THM_PROF
+          c.prof_hit++;
+#endif
         }
         rr -= chunk;
       }
@@ -1218,7 +1254,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
   if (lane == 0 && p.prof)
     {
       for (int t = 0; t < 10; t++) atomicAdd(&p.prof[t], c.prof_acc[t]);
-      for (int t = 0; t < 3; t++) atomicAdd(&p.prof[10 + t], c.prof_cols[t]);
+      for (int t = 0; t < 6; t++) atomicAdd(&p.prof[10 + t], c.prof_cols[t]);
     }
 #endif
   batch_fault |= c.fault & (FAULT_OPS_POOL | FAULT_INTERNAL);

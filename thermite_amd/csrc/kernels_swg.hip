@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256) void swg_batch_kernel(SwgBatchParams p) {
 
     SwgResult r;
     int nops;
+#ifndef THM_NO_SHORTCUT
+    if (swg_one_mismatch_shortcut(xs, 1, xlen, ys, 1, ylen, xd, opsb + ops_cap - 1, -1, (int)ops_cap, r, nops)) {
+      // result known without DP (swg_device.h)
+    } else
+#endif
     if constexpr (CPL == 0) {
       r = swg_extend_tiled(xs, 1, xlen, ys, 1, ylen, bw, xd, trace, dp, dp_stride);
       sync();

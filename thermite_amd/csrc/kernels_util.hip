@@ -77,7 +77,48 @@ __global__ void widen_kernel(const uint32_t* in, uint64_t* out, uint64_t n) {
   if (i < n) out[i] = in[i];
 }
 
+// Calibration of the memory-side counters (rocprofv3 FETCH_SIZE) on a gather of known size in the access patterns
+// of the two hot stages (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access pattern"):
+//   pattern 0  every thread loads 8 aligned bytes at a pseudo-random offset of the table (index probes);
+//   pattern 1  every thread loads 4 aligned bytes at a pseudo-random offset (suffix-array entries);
+//   pattern 2  groups of 16 lanes load 256 contiguous bytes (16 B per lane) at a pseudo-random 16-byte-aligned
+//              offset (window staging of the extend kernel).
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+__global__ __launch_bounds__(256) void calib_gather_kernel(const uint8_t* table, uint64_t span, uint64_t n_threads, int pattern,
+                                                           unsigned long long* sink) {
+  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= n_threads) return;
+  unsigned long long acc = 0;
+  if (pattern == 0) {
+    const uint64_t o = (mix64(tid) % (span / 8)) * 8;
+    acc = *(const unsigned long long*)(table + o);
+  } else if (pattern == 1) {
+    const uint64_t o = (mix64(tid) % (span / 4)) * 4;
+    acc = *(const unsigned*)(table + o);
+  } else {
+    const uint64_t o = (mix64(tid >> 4) % ((span - 256) / 16)) * 16 + (tid & 15) * 16;
+    const uint4 v = *(const uint4*)(table + o);
+    acc = v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9e3779b97f4a7c15ull) *sink = acc;  // keeps the loads alive
+}
+
 }  // namespace dev
+
+hipError_t launch_calib_gather(const uint8_t* table, uint64_t span, uint64_t n_threads, int pattern, unsigned long long* sink,
+                               hipStream_t s) {
+  if (n_threads == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::calib_gather_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, s, table, span, n_threads,
+                     pattern, sink);
+  return hipGetLastError();
+}
 
 size_t scan_tmp_entries(uint64_t n) { return (size_t)((n + dev::SCAN_TILE - 1) / dev::SCAN_TILE) + 1; }
 

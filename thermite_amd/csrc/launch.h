@@ -211,6 +211,8 @@ struct CompactParams {
 };
 hipError_t launch_compact(const CompactParams& p, hipStream_t s);
 
+hipError_t launch_calib_gather(const uint8_t* table, uint64_t span, uint64_t n_threads, int pattern, unsigned long long* sink,
+                               hipStream_t s);
 hipError_t launch_widen_u32_to_u64(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t s);
 
 }  // namespace thm

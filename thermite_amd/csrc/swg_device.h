@@ -545,6 +545,59 @@ __device__ int swg_traceback_wave(const unsigned long long* trace, int i, int j,
 
 
 // ---------------------------------------------------------------------------------------------
+// Shortcut without DP -- the commonest extension by far: the seed ended on a substitution and the rest of the
+// read matches (x[0] != y[0], x[1..] == y[1..|x|)).  Then SwgExtend::extend's result is known:
+//     score |x| - 2 at (|x|, |x|), ops = Subst, Match x (|x| - 1)
+// provided |x| >= 3 (else the maximum stays 0 at the origin), |y| >= |x|, x_drop >= 1 (no X-drop on the
+// way: the diagonal holds j - 2 in column j against a running maximum of max(0, j - 2)) and x is not one
+// repeated base.  Proof sketch (scores: match +1, mismatch -1, gap of g costs 1 + g, a leading deletion run
+// only g -- SURVEY.md Appendix A.2): a cell (i, j) scores at most i minus its penalties.  Reaching
+// |x| - 2 or more needs i >= |x| - 2 with penalties <= i - |x| + 2.  Row |x| - 2: no penalty at all, i.e.
+// the bare diagonal, which starts with the mismatch -- impossible.  Row |x| - 1: penalty <= 1, i.e. one
+// leading deletion and then x[0..|x|-1) == y[1..|x|) -- that makes x one repeated base (x[k] == y[k+1] ==
+// x[k+1]): excluded.  Row |x|: penalty <= 2: the diagonal with its one Subst (ends in column |x|), or a
+// leading deletion run of g <= 2 and an exact match behind it (ends in column |x| + g with |x| - g: g = 1
+// would beat the diagonal, but again needs x[k] == y[k+1] for all k: one repeated base), or one inserted
+// base (penalty 2) with x[1..] == y[0..]: |x| - 3.  So the maximum is |x| - 2, first attained -- in the
+// reference's scan order, columns then rows -- at (|x|, |x|); on the diagonal every cell holds i - 2 through
+// the diagonal move (any other path to (i, i) pairs a deletion with an insertion: penalty >= 3), and
+// triple_max prefers the diagonal on ties, so the trace is the diagonal.  The result depends on y[0..|x|)
+// and on |y| >= |x| only (jmax, broke).  37.7 % of the DP columns of the benchmark workload were such
+// extensions (tools/perf.py).
+__device__ __forceinline__ bool swg_one_mismatch_shortcut(const uint8_t* xs, int dx, int xlen, const uint8_t* ys, int dy,
+                                                          int ylen, int xd, uint8_t* ops, int stride, int max_ops, SwgResult& r,
+                                                          int& n_ops) {
+  if (xlen < 3 || ylen < xlen || xd < 1 || xlen > max_ops) return false;
+  const int lane = lane_id();
+  const int x0 = (int)xs[0];
+  bool bad = (lane == 0) && (x0 == (int)ys[0]);  // the shape starts with a mismatch
+  bool other = false;                            // some base of x differs from x[0]
+#pragma unroll 1
+  for (int t0 = 1; t0 < xlen; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < xlen) {
+      const int xc = (int)xs[t * dx];
+      bad = bad || xc != (int)ys[t * dy];
+      other = other || xc != x0;
+    }
+  }
+  if (__ballot(bad) != 0ull || __ballot(other) == 0ull) return false;
+  // walk order: op k belongs to the cell reached after k diagonal steps back from (|x|, |x|)
+#pragma unroll 1
+  for (int k = lane; k < xlen; k += 64) ops[k * stride] = (uint8_t)(k == xlen - 1 ? OPK_SUBST : OPK_MATCH);
+  r.score = xlen - 2;
+  r.xend = xlen;
+  r.yend = xlen;
+  r.cells = 0;
+  r.cols = 0;
+  r.jmax = xlen;
+  r.broke = true;
+  n_ops = xlen;
+  return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // Band of any width (the reference allocates whatever 2*max_band_width+1 asks for, src/swg.rs:17-26):
 // the slots of a column are walked in tiles of 64 (slot b = 64*t + lane); the column state D, C of the
 // previous and the current column lives in four wave-private int arrays of `stride` entries each

@@ -37,6 +37,8 @@ for name, opts in (("ci", capi.CI_OPTS), ("default", capi.DEFAULT_OPTS)):
     if pr.sum() > 0:
         names = ["setup", "stage", "dp", "traceback", "tree", "txprep", "lift", "emit", "final", "other"]
         tot = float(pr[:10].sum())
-        print("         DP columns: total %d, on <=32 slots %.1f%%, pairable (min of L/R when both <=32) %.1f%%" % (pr[10], 100.0 * pr[11] / max(pr[10], 1), 100.0 * pr[12] / max(pr[10], 1)), flush=True)
+        pc = lambda k: 100.0 * pr[k] / max(pr[10], 1)
+        print("         DP columns: total %d, on <=32 slots %.1f%%, pairable (min of L/R when both <=32) %.1f%%, first hit of the read %.1f%%, "
+              "transcript targets %.1f%%, one-mismatch-then-exact extensions %.1f%%" % (pr[10], pc(11), pc(12), pc(13), pc(14), pc(15)), flush=True)
         print("         extend sections: " + " ".join("%s=%.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(names, pr[:10])), flush=True)
     a.close()
