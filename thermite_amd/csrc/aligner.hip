@@ -66,6 +66,11 @@ static int get_dev_copy(thm_aligner* a) {
       e = hipMemcpyAsync(d->tx_seq.as<uint8_t>() + 16, ix->tx_seq.data(), ix->tx_seq.size(), hipMemcpyHostToDevice, s);
     up(d->exon_grid_off, ix->exon_grid_off);
     up(d->gene_grid_off, ix->gene_grid_off);
+    up(d->ref_bin, ix->ref_bin);
+    if (ix->wide)
+      up(d->ref_recs, ix->ref_recs64);
+    else
+      up(d->ref_recs, ix->ref_recs);
     if (ix->wide) {
       up(d->exon_grid, ix->exon_grid64);
       up(d->gene_grid, ix->gene_grid64);
@@ -86,12 +91,14 @@ static int get_dev_copy(thm_aligner* a) {
       v.lut = d->lut.as<LutEntryT<C>>();
       v.refs = d->refs.as<thm_ref>();
       v.name_rank = d->name_rank.as<uint32_t>();
+      v.ref_recs = d->ref_recs.as<RefRecT<C>>();
+      v.ref_bin = d->ref_bin.as<uint32_t>();
       v.txs = d->txs.as<thm_tx>();
       v.exons = d->exons.as<thm_exon>();
       v.exon_txoff = d->exon_txoff.as<uint64_t>();
       v.tx_seq = d->tx_seq.as<uint8_t>() + 16;
       v.exon_grid_off = d->exon_grid_off.as<uint32_t>();
-      v.exon_grid = d->exon_grid.as<GridEntryT<C>>();
+      v.exon_grid = d->exon_grid.as<ExonEntryT<C>>();
       v.gene_grid_off = d->gene_grid_off.as<uint32_t>();
       v.gene_grid = d->gene_grid.as<GridEntryT<C>>();
       v.n = ix->n;
@@ -183,7 +190,7 @@ void thm_aligner_free(thm_aligner* a) {
   (void)hipSetDevice(a->device);
   if (a->stream) (void)hipStreamSynchronize(a->stream);
   DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->d_cursors, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4,
-                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->r_status, &a->e_slow, &a->s_smems, &a->s_off, &a->s_cnt,
+                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->r_status, &a->e_slow, &a->e_recs, &a->s_smems, &a->s_off, &a->s_cnt,
                  &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops, &a->e_nalns,
                  &a->e_nalns64, &a->e_opbytes, &a->e_aln_off, &a->e_ops_off, &a->e_trace, &a->o_alns, &a->o_ops, &a->o_mems};
   for (DBuf* b : all) b->release();

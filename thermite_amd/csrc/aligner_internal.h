@@ -63,7 +63,7 @@ struct HBuf {
 
 struct thm_index::DevCopy {
   int device = -1;
-  DBuf text, sa, lut, refs, name_rank, txs, exons, exon_txoff, tx_seq, exon_grid_off, exon_grid, gene_grid_off, gene_grid;
+  DBuf text, sa, lut, refs, name_rank, ref_recs, ref_bin, txs, exons, exon_txoff, tx_seq, exon_grid_off, exon_grid, gene_grid_off, gene_grid;
   bool wide = false;                     // which of the two views is valid (thermite_internal.h, "Coordinate width")
   thm::DeviceIndexT<uint32_t> view;
   thm::DeviceIndexT<uint64_t> view64;
@@ -74,7 +74,7 @@ inline void free_dev_copy(thm_index::DevCopy* d) {
   int cur = 0;
   (void)hipGetDevice(&cur);
   (void)hipSetDevice(d->device);
-  DBuf* all[] = {&d->text, &d->sa,         &d->lut,    &d->refs,      &d->name_rank, &d->txs,
+  DBuf* all[] = {&d->text, &d->sa,         &d->lut,    &d->refs,      &d->name_rank, &d->ref_recs, &d->ref_bin, &d->txs,
                  &d->exons, &d->exon_txoff, &d->tx_seq, &d->exon_grid_off, &d->exon_grid, &d->gene_grid_off, &d->gene_grid};
   for (DBuf* b : all) b->release();
   (void)hipSetDevice(cur);
@@ -108,7 +108,7 @@ struct thm_aligner {
       s_work_counts, s_sel_scratch, s_heavy, s_slow;
   uint64_t smem_cap = 0;
   // extension
-  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace, e_slow;
+  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace, e_slow, e_recs;
   uint64_t n_slow_host = 0;     // reads of the slow class in the last enqueue (host count)
   uint32_t fast_max_len = 0, slow_max_len = 0;
   uint64_t cand_cap = 0, cand_ops_cap = 0;

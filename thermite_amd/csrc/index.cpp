@@ -166,6 +166,48 @@ void build_grid(const std::vector<TreeNode>& nd, int32_t root, uint64_t n, std::
               [](const GridEntry& a, const GridEntry& c) { return a.rank < c.rank; });
 }
 
+// exon grid: the same bins and order as build_grid, entries enriched with their transcript and exon (thermite_internal.h)
+template <class C>
+void build_exon_grid(const thm_index* ix, std::vector<uint32_t>& off, std::vector<ExonEntryT<C>>& entries) {
+  std::vector<GridEntryT<C>> plain;
+  build_grid<C>(ix->exon_tree, ix->exon_root, ix->n, off, plain);
+  // the plain builder keeps (start, end, tx, rank); the exon is found again through the tree node it came from:
+  // (tx, start, end) identifies an exon of a transcript unless the transcript lists the same interval twice, in
+  // which case either copy describes the same bases except for its transcript offset -- so map through nodes
+  std::vector<uint32_t> rank;
+  preorder_ranks(ix->exon_tree, ix->exon_root, rank);
+  std::vector<uint32_t> exon_of_rank(rank.size(), 0);
+  for (size_t x = 0; x < rank.size(); x++) exon_of_rank[rank[x]] = ix->exon_node_exon[x];
+  // ascending, disjoint exons in transcript order (src/index.rs:149-195) are what the fast path assumes
+  std::vector<uint8_t> tx_ascending(ix->txs.size(), 1);
+  for (size_t t = 0; t < ix->txs.size(); t++) {
+    const thm_tx& tx = ix->txs[t];
+    for (uint32_t q = 1; q < tx.n_exons; q++)
+      if (ix->exons[tx.exon_begin + q - 1].end > ix->exons[tx.exon_begin + q].start) tx_ascending[t] = 0;
+  }
+  entries.resize(plain.size());
+  for (size_t k = 0; k < plain.size(); k++) {
+    const GridEntryT<C>& g = plain[k];
+    const uint32_t gi = exon_of_rank[g.rank >> 8];
+    const thm_exon& ex = ix->exons[gi];
+    const thm_tx& tx = ix->txs[ex.tx_idx];
+    const uint32_t ei = (uint32_t)(gi - tx.exon_begin);
+    ExonEntryT<C> e;
+    e.start = g.start;
+    e.end = g.end;
+    e.value = g.value;
+    e.rank = g.rank;
+    const bool ascending = tx_ascending[ex.tx_idx] != 0;
+    e.prev_end = !ascending ? (C)~(C)0 : (ei == 0 ? (C)0 : (C)ix->exons[gi - 1].end);
+    e.txoff = (uint32_t)ix->exon_txoff[gi];
+    e.exon_idx = ei;
+    e.seq_off = tx.seq_off;
+    e.seq_len = (uint32_t)tx.seq_len;
+    e.n_exons = tx.n_exons;
+    entries[k] = e;
+  }
+}
+
 inline int base_code(uint8_t c) {
   switch (c) {
     case 'A': return 0;
@@ -457,6 +499,7 @@ static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref*
         uint32_t e = tx.strand ? k : tx.n_exons - 1 - k;
         const thm_exon& x = ix->exons[tx.exon_begin + e];
         root = a.insert(root, x.start, x.end, x.tx_idx);
+        ix->exon_node_exon.push_back((uint32_t)(tx.exon_begin + e));  // node indices are insertion order (rotations relink, never move)
       }
     }
     ix->exon_tree.swap(a.nd);
@@ -471,11 +514,39 @@ static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref*
     ix->gene_root = root;
   }
   if (wide) {
-    build_grid<uint64_t>(ix->exon_tree, ix->exon_root, n, ix->exon_grid_off, ix->exon_grid64);
+    build_exon_grid<uint64_t>(ix, ix->exon_grid_off, ix->exon_grid64);
     build_grid<uint64_t>(ix->gene_tree, ix->gene_root, n, ix->gene_grid_off, ix->gene_grid64);
   } else {
-    build_grid<uint32_t>(ix->exon_tree, ix->exon_root, n, ix->exon_grid_off, ix->exon_grid);
+    build_exon_grid<uint32_t>(ix, ix->exon_grid_off, ix->exon_grid);
     build_grid<uint32_t>(ix->gene_tree, ix->gene_root, n, ix->gene_grid_off, ix->gene_grid);
+  }
+  // idx_to_ref as two loads (thermite_internal.h, RefRecT)
+  {
+    const uint64_t nbins = (n >> GRID_SHIFT) + 1;
+    ix->ref_bin.assign(nbins, 0);
+    uint32_t r = 0;
+    for (uint64_t b = 0; b < nbins; b++) {
+      const uint64_t pos0 = b << GRID_SHIFT;
+      while (r + 1 < n_refs && ix->refs[r].end_idx <= pos0) r++;
+      ix->ref_bin[b] = r;
+    }
+    auto fill = [&](auto& v) {
+      typedef typename std::remove_reference<decltype(v)>::type::value_type R;
+      v.resize(n_refs);
+      for (uint32_t i = 0; i < n_refs; i++) {
+        R x;
+        x.start = (decltype(x.start))ix->refs[i].start_idx;
+        x.end = (decltype(x.end))ix->refs[i].end_idx;
+        x.len = (decltype(x.len))ix->refs[i].len;
+        x.name_rank = ix->name_rank[i];
+        x.strand = ix->refs[i].strand ? 1u : 0u;
+        v[i] = x;
+      }
+    };
+    if (wide)
+      fill(ix->ref_recs64);
+    else
+      fill(ix->ref_recs);
   }
   ix->dev_mu = new std::mutex();
   *out = ix;

@@ -59,25 +59,22 @@ struct RefInfoT {
   uint32_t name_rank;
   bool strand;
 };
-// Index::idx_to_ref: refs.partition_point(|x| x.end_idx <= idx)
+// Index::idx_to_ref: refs.partition_point(|x| x.end_idx <= idx) -- answered in two loads: the contig copy that
+// holds the first symbol of idx's bin, then forward over the (rare) boundaries inside the bin
 template <class C, class IX>
 __device__ RefInfoT<C> idx_to_ref(const IX& ix, C idx) {
-  uint32_t lo = 0, hi = ix.n_refs;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if ((C)uload(&ix.refs[mid].end_idx) <= idx)
-      lo = mid + 1;
-    else
-      hi = mid;
+  uint32_t lo = uload(&ix.ref_bin[idx >> GRID_SHIFT]);
+  RefRecT<C> r = uload(&ix.ref_recs[lo]);
+  while (r.end <= idx && lo + 1 < ix.n_refs) {
+    lo++;
+    r = uload(&ix.ref_recs[lo]);
   }
-  if (lo >= ix.n_refs) lo = ix.n_refs - 1;
-  const thm_ref r = uload(&ix.refs[lo]);
   RefInfoT<C> o;
-  o.start = (C)r.start_idx;
-  o.end = (C)r.end_idx;
-  o.len = (C)r.len;
+  o.start = r.start;
+  o.end = r.end;
+  o.len = r.len;
   o.id = lo;
-  o.name_rank = uload(&ix.name_rank[lo]);
+  o.name_rank = r.name_rank;
   o.strand = r.strand != 0;
   return o;
 }
@@ -142,9 +139,9 @@ enum { PS_SETUP = 0, PS_STAGE = 1, PS_DP = 2, PS_TRACEBACK = 3, PS_TREE = 4, PS_
 // [qs, qe) come out in IntervalTree::find order, i.e. by ascending pre-order rank.
 // Up to 64 candidate entries sit one per lane in registers; larger candidate sets
 // (dense loci) are re-read from memory on every step.
-template <class C>
+template <class C, class E>
 struct GridQueryT {
-  const GridEntryT<C>* ent;  // candidates [0, cnt)
+  const E* ent;  // candidates [0, cnt): GridEntryT<C> (genes) or ExonEntryT<C> (exons)
   uint32_t cnt;
   C qs, qe;
   uint32_t b0;
@@ -152,15 +149,15 @@ struct GridQueryT {
   int my_rank;  // this lane's candidate: its rank if it overlaps and is the primary copy, else -1
   uint32_t my_val;
 };
-template <class C>
-__device__ __forceinline__ int grid_entry_rank(const GridEntryT<C>& e, C qs, C qe, uint32_t b0) {
+template <class C, class E>
+__device__ __forceinline__ int grid_entry_rank(const E& e, C qs, C qe, uint32_t b0) {
   const bool overlap = qs < e.end && e.start < qe;
   const uint32_t home = max(b0, (uint32_t)(e.start >> GRID_SHIFT));  // first queried bin this interval is listed in
   const bool primary = (e.rank & 0xffu) == (home & 0xffu);
   return (overlap && primary) ? (int)(e.rank >> 8) : -1;
 }
-template <class C>
-__device__ void grid_begin(GridQueryT<C>& g, const uint32_t* off, const GridEntryT<C>* entries, C qs, C qe) {
+template <class C, class E>
+__device__ void grid_begin(GridQueryT<C, E>& g, const uint32_t* off, const E* entries, C qs, C qe) {
   const uint32_t b0 = (uint32_t)(qs >> GRID_SHIFT), b1 = (uint32_t)((qe > qs ? qe - 1 : qs) >> GRID_SHIFT);
   const uint32_t e0 = uload(&off[b0]), e1 = uload(&off[b1 + 1]);
   g.ent = entries + e0;
@@ -172,14 +169,23 @@ __device__ void grid_begin(GridQueryT<C>& g, const uint32_t* off, const GridEntr
   g.my_rank = -1;
   g.my_val = 0;
   if (g.cnt <= 64 && (uint32_t)lane_id() < g.cnt) {
-    const GridEntryT<C> e = g.ent[lane_id()];
-    g.my_rank = grid_entry_rank<C>(e, qs, qe, b0);
-    g.my_val = e.value;
+    const E* e = &g.ent[lane_id()];
+    // the four leading fields only (an exon entry carries more: read by the caller for the one entry that wins)
+    struct Head {
+      C start, end;
+      uint32_t value, rank;
+    } h;
+    h.start = e->start;
+    h.end = e->end;
+    h.value = e->value;
+    h.rank = e->rank;
+    g.my_rank = grid_entry_rank<C>(h, qs, qe, b0);
+    g.my_val = h.value;
   }
 }
-// next overlapping interval in yield order; false when exhausted
-template <class C>
-__device__ bool grid_next(GridQueryT<C>& g, uint32_t& value) {
+// next overlapping interval in yield order (its value and its index among the candidates); false when exhausted
+template <class C, class E>
+__device__ bool grid_next(GridQueryT<C, E>& g, uint32_t& value, uint32_t& ent_idx) {
   const int BIG = 0x0fffffff;
   if (g.cnt == 0) return false;
   if (g.cnt <= 64) {
@@ -187,32 +193,44 @@ __device__ bool grid_next(GridQueryT<C>& g, uint32_t& value) {
     const int best = wave_min(cand);
     if (best == BIG) return false;
     const unsigned long long m = __ballot(g.my_rank == best);
-    value = (uint32_t)__builtin_amdgcn_readlane((int)g.my_val, __builtin_ctzll(m));
+    ent_idx = (uint32_t)__builtin_ctzll(m);
+    value = (uint32_t)__builtin_amdgcn_readlane((int)g.my_val, (int)ent_idx);
     g.last = best;
     return true;
   }
   int best = BIG;
-  uint32_t bval = 0;
+  uint32_t bval = 0, bidx = 0;
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < g.cnt; c0 += 64) {
     const uint32_t i = c0 + (uint32_t)lane_id();
     int r = -1;
     uint32_t v = 0;
     if (i < g.cnt) {
-      const GridEntryT<C> e = g.ent[i];
-      r = grid_entry_rank<C>(e, g.qs, g.qe, g.b0);
-      v = e.value;
+      const E* e = &g.ent[i];
+      struct Head {
+        C start, end;
+        uint32_t value, rank;
+      } h;
+      h.start = e->start;
+      h.end = e->end;
+      h.value = e->value;
+      h.rank = e->rank;
+      r = grid_entry_rank<C>(h, g.qs, g.qe, g.b0);
+      v = h.value;
     }
     const int cand = (r > g.last) ? r : BIG;
     const int cb = wave_min(cand);
     if (cb < best) {
       best = cb;
       const unsigned long long m = __ballot(cand == cb);
-      bval = (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_ctzll(m));
+      const int wl = (int)__builtin_ctzll(m);
+      bval = (uint32_t)__builtin_amdgcn_readlane((int)v, wl);
+      bidx = c0 + (uint32_t)wl;
     }
   }
   if (best == BIG) return false;
   value = bval;
+  ent_idx = bidx;
   g.last = best;
   return true;
 }
@@ -665,16 +683,11 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
   unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
   int batch_fault = 0;
 
-  // Reads are handed out by atomic counters, QCHUNK at a time.  Small chunks balance the waves
+  // Reads are handed out by atomic counters, one at a time.  Small chunks balance the waves
   // (the cost per read varies by orders of magnitude: repeats), but one hot word serves only ~88 M
   // returning atomics per second; so there are EXT_NQ counters on separate cache lines, each over
   // its own contiguous share of the batch, and a wave that finds its counter exhausted moves on to
   // the next one.
-#ifndef THM_EXT_QCHUNK
-#define THM_EXT_QCHUNK 1
-#endif
-  constexpr unsigned QCHUNK = THM_EXT_QCHUNK;
-  unsigned q_next = 0, q_end = 0;
   const bool list_only = GS || p.list_only != 0;
   const unsigned n_total = list_only ? 0u : (unsigned)p.reads.n_reads;
   const unsigned q_share = (n_total + EXT_NQ - 1) / EXT_NQ;
@@ -687,45 +700,43 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
   bool heavy_phase = true;
   const unsigned n_heavy = (unsigned)uload(p.heavy_count);
   const unsigned list_q = (GS ? EXT_NQ + 1 : EXT_NQ) * EXT_QSTRIDE;
+  // (Issuing the atomic for the next read while the current one is worked on was tried: the pending return value
+  // stays live across the whole hit loop and costs 400 bytes per lane of spills -- three times slower.)
   for (;;) {
-    bool from_heavy = false;
-    if (q_next == q_end) {
-      bool got = false;
-      if (heavy_phase) {
-        unsigned g = 0;
-        if (lane == 0) g = atomicAdd(p.queue + list_q, 1u);
-        g = (unsigned)bcast_first((int)g);
-        if (g < n_heavy) {
-          q_next = (unsigned)uload(&p.heavy[g]);
-          q_end = q_next + 1;
-          got = true;
-          from_heavy = true;
-        } else {
-          heavy_phase = false;
-        }
+    bool from_heavy = false, got = false;
+    unsigned idx = 0;
+    if (!got && heavy_phase) {
+      unsigned g = 0;
+      if (lane == 0) g = atomicAdd(p.queue + list_q, 1u);
+      g = (unsigned)bcast_first((int)g);
+      if (g < n_heavy) {
+        idx = (unsigned)uload(&p.heavy[g]);
+        got = true;
+        from_heavy = true;
+      } else {
+        heavy_phase = false;
       }
-      while (!got && q_tried < EXT_NQ && n_total) {
-        unsigned g = 0;
-        if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, QCHUNK);
-        g = (unsigned)bcast_first((int)g);
-        const unsigned lo = my_q * q_share, hi = min(lo + q_share, n_total);
-        if (lo < hi && g < hi - lo) {
-          q_next = lo + g;
-          q_end = min(q_next + QCHUNK, hi);
-          got = true;
-          break;
-        }
-        my_q = (my_q + 1) % EXT_NQ;
-        q_tried++;
-      }
-      if (!got) break;
     }
-    const unsigned idx = q_next++;
-    const uint64_t r0 = uload(&p.reads.offsets[idx]);
-    const uint64_t Lfull = uload(&p.reads.offsets[idx + 1]) - r0;
+    while (!got && q_tried < EXT_NQ && n_total) {
+      unsigned g = 0;
+      if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, 1u);
+      g = (unsigned)bcast_first((int)g);
+      const unsigned lo = my_q * q_share, hi = min(lo + q_share, n_total);
+      if (lo < hi && g < hi - lo) {
+        idx = lo + g;
+        got = true;
+        break;
+      }
+      my_q = (my_q + 1) % EXT_NQ;
+      q_tried++;
+    }
+    if (!got) break;
+    // everything needed to start on the read, in one scalar load (launch.h, ReadRecT)
+    const ReadRecT<C> rec = uload(&p.read_recs[idx]);
     // not this launch's read: the slow class (and reads beyond every class) are listed by plan_kernel
-    if (Lfull > (uint64_t)p.max_read_len) continue;
-    const int L = (int)Lfull;
+    if (rec.len > p.max_read_len) continue;
+    const uint64_t r0 = rec.base_off;
+    const int L = (int)rec.len;
     c.L = L;
     #pragma unroll 1
     for (int t = lane; t < (int)lcap; t += 64) c.rd[t] = (t < L) ? p.reads.bases[r0 + t] : (uint8_t)0;  // already upper-cased and sanitised
@@ -745,18 +756,18 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       band_width = x_drop = 0;
     }
 
-    const uint64_t cand0 = uload(&p.read_cand_off[idx]);
+    const uint64_t cand0 = rec.cand_off;
     Cand* cands = p.cands + cand0;
     uint32_t* order = p.order + 2 * cand0;  // two scratch lists of the read's hit count each
-    const uint64_t n_hits_cap = uload(&p.read_cand_off[idx + 1]) - cand0;
+    const uint64_t n_hits_cap = rec.n_hits;
     if (!GS && !from_heavy && n_hits_cap >= HEAVY_HITS) continue;  // went out with the heavy reads
     uint32_t n_acc = 0;
     unsigned acc_bytes = 0;  // op bytes and type of the most recent accepted candidate
     int acc_type = 0;
 
     PROF_MARK(c, PS_SETUP);
-    const uint64_t s0 = uload(&p.read_smem_off[idx]);
-    uint32_t n_sm = uload(&p.read_smem_cnt[idx]);
+    const uint64_t s0 = rec.smem_off;
+    uint32_t n_sm = rec.smem_cnt;
     if (cand0 + n_hits_cap > p.cand_cap) {  // candidate pool too small: the host grows it and reruns
       c.fault |= FAULT_OPS_POOL;
       n_sm = 0;
@@ -765,13 +776,24 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
     c.prof_hit = 0;
 #endif
     for (uint32_t si = 0; si < n_sm; si++) {
-      const SmemT<C> sm = uload(&p.smems[s0 + si]);
+      SmemT<C> sm;
+      if (si == 0) {  // the first SMEM travels in the read's record
+        sm.lo = rec.lo0;
+        sm.hi = rec.hi0;
+        sm.qpos = rec.qpos0;
+        sm.len = rec.len0;
+      } else {
+        sm = uload(&p.smems[s0 + si]);
+      }
       const int q = sm.qpos, len = sm.len;
       C rr = sm.hi;
       while (rr > sm.lo) {
         const uint32_t chunk = (uint32_t)min((C)64, (C)(rr - sm.lo));
         C my_sa = 0;
-        if ((uint32_t)lane < chunk) my_sa = ix.sa[rr - 1 - lane];
+        if (si == 0 && rr == sm.hi && chunk == 1)
+          my_sa = rec.sa0;  // ... and so does its first (here: only) occurrence
+        else if ((uint32_t)lane < chunk)
+          my_sa = ix.sa[rr - 1 - lane];
         for (uint32_t t = 0; t < chunk; t++) {
           const S hr = (S)readlane_c(my_sa, bcast_first((int)t));
           // ================= align_seed_hit (src/aligner.rs:198-314) =================
@@ -802,12 +824,13 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
           uint8_t* best_buf = c.pc;
           bool genome_done = false;
           LrMemo gmemo, tmemo;
-          GridQueryT<C> eg;
+          GridQueryT<C, ExonEntryT<C>> eg;
+          uint32_t best_ent = 0;  // the exon-grid entry the best transcript was reached through
           for (;;) {
             S win0, lo_abs, hi_abs, t_r;
             int t_q, t_len;
             uint8_t* buf;
-            uint32_t tx_idx = 0;
+            uint32_t tx_idx = 0, cur_ent = 0;
             if (!genome_done) {
               // genome window (:212-215)
               const S rs = (S)ref.start;
@@ -833,30 +856,48 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
               buf = c.pa;
             } else {
               // next interval exon_to_tx.find would yield (interval grid, same order)
-              const bool found = grid_next(eg, tx_idx);
+              uint32_t ent_idx = 0;
+              const bool found = grid_next(eg, tx_idx, ent_idx);
               PROF_MARK(c, PS_TREE);
               if (!found) break;
-              const thm_tx tx = uload(&ix.txs[tx_idx]);
-              // lift_mem_to_tx (src/txome.rs:82-103): first exon in transcript order that intersects
-              int fe = -1;
-              for (uint32_t e0 = 0; e0 < tx.n_exons && fe < 0; e0 += 64) {
-                const uint32_t e = e0 + (uint32_t)lane;
-                bool hit = false;
-                if (e < tx.n_exons) {
-                  const thm_exon x = ix.exons[tx.exon_begin + e];
-                  const C x0 = (C)x.start, x1 = (C)x.end;
-                  hit = (qs >= x0 && qs < x1) || (x0 >= qs && x0 < qe);
+              cur_ent = ent_idx;
+              // the entry carries what is needed of its transcript and exon (thermite_internal.h, ExonEntryT)
+              const ExonEntryT<C> ge = uload(&eg.ent[ent_idx]);
+              S xs, xe;
+              int exon_sum;
+              thm_tx tx;
+              tx.seq_off = ge.seq_off;
+              tx.seq_len = ge.seq_len;
+              if (ge.prev_end <= qs) {
+                // lift_mem_to_tx (src/txome.rs:82-103): this exon is the first of its transcript that intersects the seed
+                xs = (S)ge.start;
+                xe = (S)ge.end;
+                exon_sum = (int)ge.txoff;
+              } else {
+                // the previous exon reaches into the seed (a seed across a short intron), or the exons of this transcript
+                // do not ascend: first exon in transcript order that intersects, by looking at them all
+                tx = uload(&ix.txs[tx_idx]);
+                int fe = -1;
+                for (uint32_t e0 = 0; e0 < tx.n_exons && fe < 0; e0 += 64) {
+                  const uint32_t e = e0 + (uint32_t)lane;
+                  bool hit = false;
+                  if (e < tx.n_exons) {
+                    const thm_exon x = ix.exons[tx.exon_begin + e];
+                    const C x0 = (C)x.start, x1 = (C)x.end;
+                    hit = (qs >= x0 && qs < x1) || (x0 >= qs && x0 < qe);
+                  }
+                  const unsigned long long m = __ballot(hit);
+                  if (m) fe = (int)e0 + __builtin_ctzll(m);
                 }
-                const unsigned long long m = __ballot(hit);
-                if (m) fe = (int)e0 + __builtin_ctzll(m);
+                if (fe < 0) {  // unreachable!() in the reference
+                  c.fault |= FAULT_CONTRACT;
+                  continue;
+                }
+                const thm_exon x = uload(&ix.exons[tx.exon_begin + fe]);
+                exon_sum = (int)uload(&ix.exon_txoff[tx.exon_begin + fe]);
+                xs = (S)x.start;
+                xe = (S)x.end;
               }
-              if (fe < 0) {  // unreachable!() in the reference
-                c.fault |= FAULT_CONTRACT;
-                continue;
-              }
-              const thm_exon x = uload(&ix.exons[tx.exon_begin + fe]);
-              const int exon_sum = (int)uload(&ix.exon_txoff[tx.exon_begin + fe]);
-              const S xs = (S)x.start, xe = (S)x.end;
               int tr_ = (int)((hr > xs) ? hr - xs : (S)0) + exon_sum;
               const int start_offset = (int)((xs > hr) ? xs - hr : (S)0);
               const int t_end = (int)(min(hr + (S)len, xe) - xs) + exon_sum;
@@ -971,6 +1012,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
               if (!have_best || pth.score > best.score) {  // strictly better (:249)
                 have_best = true;
                 best_tx = tx_idx;
+                best_ent = cur_ent;
                 best = pth;
                 uint8_t* tmp = cur_buf;
                 cur_buf = best_buf;
@@ -1011,22 +1053,40 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
           bool accept = intron_mode || exonic;
           if (sc < p.opts.min_aln_score || sc < min_aln_score || sc < max_aln_score - range) accept = false;
           if (accept) {
+            uint32_t best_tlen = 0;
             if (exonic) {
-              g_ny = lift_markers<S>(c, ix, uload(&ix.txs[best_tx]), best_buf, best.nops, best.xend < L, (int)best.ystart,
-                                     (int)best.yend, cy0, cy1);
+              // lift_tx_to_gx (src/txome.rs:110-160).  An alignment that stays inside the exon its seed was lifted through
+              // has no intron to insert: its ends move by the exon's offset.  (Ending exactly on the exon's last base
+              // still receives the intron when a clip follows, :132-141 -- that case takes the general path.)
+              const ExonEntryT<C> ge = uload(&eg.ent[best_ent]);
+              best_tlen = ge.seq_len;
+              const int ys_ = (int)best.ystart, ye_ = (int)best.yend;
+              const int e_lo = (int)ge.txoff, e_hi = e_lo + (int)(ge.end - ge.start);
+              const bool inside = ge.prev_end <= qs && ys_ >= e_lo && ys_ < e_hi &&
+                                  (ye_ < e_hi || (ye_ == e_hi && (ge.exon_idx + 1 >= ge.n_exons || !(best.xend < L))));
+              if (inside) {
+                cy0 = (S)ge.start + (S)(ys_ - e_lo);
+                cy1 = (S)ge.start + (S)(ye_ - e_lo);
+                g_ny = 0;
+                PROF_MARK(c, PS_LIFT);
+              } else {
+                g_ny = lift_markers<S>(c, ix, uload(&ix.txs[best_tx]), best_buf, best.nops, best.xend < L, ys_, ye_, cy0, cy1);
+              }
             } else {
               // first interval gene_intervals.find yields (:283-288, :306); only reached in intron mode
-              GridQueryT<C> gg;
+              GridQueryT<C, GridEntryT<C>> gg;
               grid_begin<C>(gg, ix.gene_grid_off, ix.gene_grid, (C)cy0, (C)cy1);
-              uint32_t gene = 0;
-              if (grid_next(gg, gene)) {
+              uint32_t gene = 0, gene_ent = 0;
+              if (grid_next(gg, gene, gene_ent)) {
                 aln_type = THM_ALN_INTRONIC;
                 type_idx = gene;
               }
               PROF_MARK(c, PS_TREE);
             }
-            // concat_to_chr_aln (:429-449)
-            const RefInfoT<C> cref = idx_to_ref<C>(ix, (C)cy0);
+            // concat_to_chr_aln (:429-449).  Index::idx_to_ref(ystart): the alignment starts inside the contig copy of
+            // its hit (the genome window is clamped to it, a transcript's exons lie on one copy), so the lookup is the
+            // hit's own; anything else goes through the search.
+            const RefInfoT<C> cref = ((C)cy0 >= ref.start && (C)cy0 < ref.end) ? ref : idx_to_ref<C>(ix, (C)cy0);
             uint64_t ch0, ch1;
             bool rev;
             if (cref.strand) {
@@ -1069,7 +1129,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
               if (exonic) {
                 cd.tx_ystart = (uint64_t)best.ystart;
                 cd.tx_yend = (uint64_t)best.yend;
-                cd.tx_ylen = uload(&ix.txs[best_tx].seq_len);
+                cd.tx_ylen = best_tlen;
                 cd.tx_ops_off = toff2;
                 cd.tx_ops_len = (uint32_t)tnb;
                 cd.tx_score = best.score;

@@ -759,6 +759,33 @@ __global__ __launch_bounds__(256) void plan_kernel(PlanParams p) {
   block_append(slow, r, p.slow, &p.counts[5]);
 }
 
+// One record per read for the extend kernel (launch.h, ReadRecT): thread per read
+template <class C>
+__global__ __launch_bounds__(256) void pack_reads_kernel(PackParamsT<C> p) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= p.n_reads) return;
+  ReadRecT<C> rec;
+  const uint64_t b0 = p.offsets[r], L = p.offsets[r + 1] - b0;
+  rec.base_off = b0;
+  rec.len = L > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)L;
+  rec.smem_off = p.read_smem_off[r];
+  rec.smem_cnt = p.read_smem_cnt[r];
+  const uint64_t c0 = p.read_cand_off[r], nh = p.read_cand_off[r + 1] - c0;
+  rec.cand_off = c0;
+  rec.n_hits = nh > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nh;
+  rec.qpos0 = rec.len0 = 0;
+  rec.lo0 = rec.hi0 = rec.sa0 = 0;
+  if (rec.smem_cnt > 0 && *p.fault_seed == 0) {  // after a pool overflow the runs are incomplete (the batch is replayed)
+    const SmemT<C> sm = p.smems[rec.smem_off];
+    rec.qpos0 = sm.qpos;
+    rec.len0 = sm.len;
+    rec.lo0 = sm.lo;
+    rec.hi0 = sm.hi;
+    if (sm.hi > sm.lo) rec.sa0 = p.sa[sm.hi - 1];
+  }
+  p.recs[r] = rec;
+}
+
 // Mem list of Index::all_smems for thm_smems_batch: one wave per read
 template <class C>
 __global__ __launch_bounds__(256) void expand_kernel(ExpandParamsT<C> p) {
@@ -866,6 +893,15 @@ hipError_t launch_plan(const PlanParams& p, hipStream_t s) {
   hipLaunchKernelGGL(dev::plan_kernel, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, s, p);
   return hipGetLastError();
 }
+
+template <class C>
+static hipError_t launch_pack_reads_t(const PackParamsT<C>& p, hipStream_t s) {
+  if (p.n_reads == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::pack_reads_kernel<C>, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+hipError_t launch_pack_reads(const PackParamsT<uint32_t>& p, hipStream_t s) { return launch_pack_reads_t(p, s); }
+hipError_t launch_pack_reads(const PackParamsT<uint64_t>& p, hipStream_t s) { return launch_pack_reads_t(p, s); }
 
 template <class C>
 static hipError_t launch_expand_t(const ExpandParamsT<C>& p, hipStream_t s) {

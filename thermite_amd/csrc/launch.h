@@ -107,6 +107,37 @@ struct PlanParams {
 };
 hipError_t launch_plan(const PlanParams& p, hipStream_t s);
 
+// Everything the extend kernel needs to start on a read, in one 64-byte record (one scalar load instead of a chain of
+// dependent ones: offsets, SMEM run, candidate slice, first SMEM, its first suffix-array entry).  Written by
+// pack_reads_kernel after the seed stage and the hit-count scan.
+template <class C>
+struct ReadRecT {
+  uint64_t base_off;   // first base of the read in the sanitised batch
+  uint64_t smem_off;   // the read's SMEM run in the pool
+  uint64_t cand_off;   // the read's slice of cands[] (and, doubled, of order[])
+  uint32_t len;        // read length; > max length of every class: 0xFFFFFFFF
+  uint32_t smem_cnt;
+  uint32_t n_hits;     // min(seed hits, 2^32 - 1): size of the slice
+  uint16_t qpos0, len0;  // the first SMEM of the run ...
+  C lo0, hi0;
+  C sa0;               // ... and its first occurrence in align_read's order, sa[hi0 - 1]
+};
+static_assert(sizeof(ReadRecT<uint32_t>) == 56 && sizeof(ReadRecT<uint64_t>) == 64, "ReadRec layout");
+template <class C>
+struct PackParamsT {
+  const C* sa;
+  const uint64_t* offsets;
+  uint64_t n_reads;
+  const SmemT<C>* smems;
+  const uint64_t* read_smem_off;
+  const uint32_t* read_smem_cnt;
+  const uint64_t* read_cand_off;  // [n_reads + 1]
+  const int* fault_seed;
+  ReadRecT<C>* recs;
+};
+hipError_t launch_pack_reads(const PackParamsT<uint32_t>& p, hipStream_t s);
+hipError_t launch_pack_reads(const PackParamsT<uint64_t>& p, hipStream_t s);
+
 // expand SMEMs into Mem lists (thm_smems_batch)
 template <class C>
 struct ExpandParamsT {
@@ -157,9 +188,7 @@ struct ExtendParamsT {
   ReadBatch reads;
   thm_align_opts opts;
   const SmemT<C>* smems;
-  const uint64_t* read_smem_off;
-  const uint32_t* read_smem_cnt;
-  const uint64_t* read_cand_off;  // exclusive prefix sum of read_hits: the read's slice of cands[]
+  const ReadRecT<C>* read_recs;   // [n_reads] (pack_reads_kernel)
   const unsigned long long* heavy;        // the list this launch goes through first: reads with >= HEAVY_HITS hits
   const unsigned long long* heavy_count;  // (fast kernel) or the reads of the slow class and the retries (any-width kernel)
   Cand* cands;

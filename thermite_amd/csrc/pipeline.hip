@@ -197,9 +197,22 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   ep.reads.n_reads = n;
   ep.opts = a->opts;
   ep.smems = a->s_smems.as<SmemT<C>>();
-  ep.read_smem_off = a->s_off.as<uint64_t>();
-  ep.read_smem_cnt = a->s_cnt.as<uint32_t>();
-  ep.read_cand_off = a->s_cand_off.as<uint64_t>();
+  // one record per read (offsets, SMEM run, candidate slice, first SMEM and its first occurrence)
+  HIPCHK(a, a->e_recs.ensure((n + 1) * sizeof(ReadRecT<C>)));
+  {
+    PackParamsT<C> pk;
+    pk.sa = ep.ix.sa;
+    pk.offsets = a->r_offsets.as<uint64_t>();
+    pk.n_reads = n;
+    pk.smems = ep.smems;
+    pk.read_smem_off = a->s_off.as<uint64_t>();
+    pk.read_smem_cnt = a->s_cnt.as<uint32_t>();
+    pk.read_cand_off = a->s_cand_off.as<uint64_t>();
+    pk.fault_seed = a->d_fault.as<int>();
+    pk.recs = a->e_recs.as<ReadRecT<C>>();
+    HIPCHK(a, launch_pack_reads(pk, s));
+  }
+  ep.read_recs = a->e_recs.as<ReadRecT<C>>();
   ep.heavy = a->s_heavy.as<unsigned long long>();
   ep.heavy_count = a->s_work_counts.as<unsigned long long>() + 2;
   ep.cands = a->e_cands.as<Cand>();

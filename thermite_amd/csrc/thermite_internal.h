@@ -52,6 +52,37 @@ struct GridEntryT {
 };
 static_assert(sizeof(GridEntryT<uint32_t>) == 16 && sizeof(GridEntryT<uint64_t>) == 24, "GridEntry layout");
 
+// Entry of the exon grid (exon_to_tx): the interval is one exon of one transcript, and the entry carries what
+// align_seed_hit needs from that transcript and exon, so that the common case (the seed lies in this exon, the
+// alignment stays inside it) costs no further dependent loads of transcript and exon records:
+//   lift_mem_to_tx (src/txome.rs:82-103) takes the FIRST exon in transcript order that intersects the seed; exons of a
+//   transcript ascend in concatenated coordinates (src/index.rs:149-195), so that is this exon unless the previous
+//   exon reaches into the seed (prev_end > seed start; an index whose exons do not ascend sets prev_end to the
+//   maximum, which always takes the general path).
+template <class C>
+struct ExonEntryT {
+  C start, end;
+  uint32_t value;     // tx_idx
+  uint32_t rank;      // as in GridEntryT
+  C prev_end;         // end of the previous exon of the transcript, 0 if this is its first
+  uint32_t txoff;     // transcript offset of the exon's first base (exon_txoff)
+  uint32_t exon_idx;  // index of the exon within the transcript
+  uint64_t seq_off;   // Tx::seq = tx_seq[seq_off .. seq_off + seq_len)
+  uint32_t seq_len;
+  uint32_t n_exons;
+};
+static_assert(sizeof(ExonEntryT<uint32_t>) == 48 && sizeof(ExonEntryT<uint64_t>) == 56, "ExonEntry layout");
+
+// Index::idx_to_ref without a search: ref_bin[idx >> GRID_SHIFT] is the contig copy that holds the first symbol of
+// the bin (the one that holds idx is that one or, when a boundary falls into the bin, a later one), RefRecT what
+// the kernels need of a Ref (src/index.rs:391-399) in one load.
+template <class C>
+struct RefRecT {
+  C start, end, len;
+  uint32_t name_rank;
+  uint32_t strand;
+};
+
 // k-mer prefix table entry: suffix-array interval of one ACGT-only kt-mer
 template <class C>
 struct LutEntryT {
@@ -67,12 +98,14 @@ struct DeviceIndexT {
   const LutEntryT<C>* lut;  // 4^kt
   const thm_ref* refs;
   const uint32_t* name_rank;  // per ref
+  const RefRecT<C>* ref_recs;  // per ref
+  const uint32_t* ref_bin;     // [n_bins]
   const thm_tx* txs;
   const thm_exon* exons;
   const uint64_t* exon_txoff;  // per exon: offset of its first base in the transcript
   const uint8_t* tx_seq;
   const uint32_t* exon_grid_off;  // [n_bins + 1]
-  const GridEntryT<C>* exon_grid;
+  const ExonEntryT<C>* exon_grid;
   const uint32_t* gene_grid_off;
   const GridEntryT<C>* gene_grid;
   uint64_t n;
@@ -119,8 +152,14 @@ struct thm_index {
   std::vector<thm::TreeNode> exon_tree, gene_tree;
   int32_t exon_root = -1, gene_root = -1;
   std::vector<uint32_t> exon_grid_off, gene_grid_off;
-  std::vector<thm::GridEntryT<uint32_t>> exon_grid, gene_grid;
-  std::vector<thm::GridEntryT<uint64_t>> exon_grid64, gene_grid64;
+  std::vector<thm::ExonEntryT<uint32_t>> exon_grid;
+  std::vector<thm::ExonEntryT<uint64_t>> exon_grid64;
+  std::vector<thm::GridEntryT<uint32_t>> gene_grid;
+  std::vector<thm::GridEntryT<uint64_t>> gene_grid64;
+  std::vector<uint32_t> exon_node_exon;  // exon_tree node -> index into exons[]
+  std::vector<uint32_t> ref_bin;
+  std::vector<thm::RefRecT<uint32_t>> ref_recs;
+  std::vector<thm::RefRecT<uint64_t>> ref_recs64;
   uint64_t n = 0;
   // names for the writer (Ref::name, Tx::id, Gene::{id,name}); empty when not supplied
   std::vector<std::string> contig_names, tx_ids, gene_ids, gene_names;
