@@ -79,6 +79,19 @@ __device__ RefInfoT<C> idx_to_ref(const IX& ix, C idx) {
   return o;
 }
 
+// What retain / filter_overlapping / the final sort (src/aligner.rs:177-187) look at, per accepted candidate: kept in
+// LDS for the first KEYCAP candidates of a read, so that the usual multi-candidate read (a handful) is finished
+// from registers without going back to the candidate array in global memory.
+struct CandKey {
+  uint64_t ystart, yend;
+  int32_t score;
+  uint32_t name_rank;
+  uint32_t bytes;        // serialised op bytes (genome + transcript streams)
+  uint32_t strand_type;  // strand | aln_type << 8
+};
+static_assert(sizeof(CandKey) == 32, "CandKey layout");
+constexpr int KEYCAP = 16;
+
 // wave-private buffers: LDS in the register-resident kernels, a slice of global memory in the any-width
 // kernel (GS).  Lanes exchange data through them, so every exchange is followed by wsync(): a wavefront-scope
 // fence for LDS, a workgroup-scope one (waits for the stores; same-CU L1 is coherent) for global memory.
@@ -96,6 +109,7 @@ struct WctxT {
   int* mk_k;      // intron markers of the alignment being emitted: op index they precede ...
   uint32_t* ycl;  // ... and their lengths
   int mk_cap;
+  CandKey* ck;    // keys of the first KEYCAP accepted candidates (register-resident kernels only)
   int* dp;        // any-width kernel: column state of swg_extend_tiled (4 arrays of dp_stride ints)
   int dp_stride;
   int L, opcap, wcap;
@@ -644,8 +658,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
     c.dp = (int*)(base + sl.dp);
     c.dp_stride = (int)sl.dp_stride;
     c.mk_cap = (int)p.mk_cap;
+    c.ck = nullptr;
   } else {
-    const uint32_t per_wave = lcap + 2u * wcap + caps.trb + 3u * opcap + 8u * FAST_MAX_YCLIPS;
+    const uint32_t per_wave = lcap + 2u * wcap + caps.trb + 3u * opcap + 8u * FAST_MAX_YCLIPS + (uint32_t)(KEYCAP * sizeof(CandKey));
     uint8_t* base = smem + (size_t)wave * per_wave;
     c.rd = base;
     c.win = c.rd + lcap;
@@ -657,6 +672,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
     c.pc = c.pb + opcap;
     c.mk_k = (int*)(c.pc + opcap);
     c.ycl = (uint32_t*)(c.mk_k + FAST_MAX_YCLIPS);
+    c.ck = (CandKey*)(c.ycl + FAST_MAX_YCLIPS);
     c.dp = nullptr;
     c.dp_stride = 0;
     c.mk_cap = FAST_MAX_YCLIPS;
@@ -1137,6 +1153,16 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
                 cd.tx_xend = (uint32_t)best.xend;
               }
               cands[n_acc] = cd;
+              if (!GS && n_acc < (uint32_t)KEYCAP) {
+                CandKey k;
+                k.ystart = ch0;
+                k.yend = ch1;
+                k.score = sc;
+                k.name_rank = ref.name_rank;
+                k.bytes = (uint32_t)(nb + tnb);
+                k.strand_type = (ref.strand ? 1u : 0u) | ((uint32_t)aln_type << 8);
+                c.ck[n_acc] = k;
+              }
             }
             n_acc++;
             acc_bytes = (unsigned)(nb + tnb);
@@ -1156,6 +1182,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       }
     }
     PROF_MARK(c, PS_OTHER);
+#ifdef THM_PROF_FINAL
+    const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+#endif
     // per-read outcomes that are not alignments
     if (c.fault & FAULT_RETRY) {
       // more introns in one alignment than this kernel's marker list holds: the any-width kernel redoes the read
@@ -1177,6 +1206,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       }
     }
     batch_fault |= c.fault;
+#ifdef THM_PROF_FINAL
+    const unsigned long long tf1 = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t nres = 0;
     unsigned long long opb = 0;
     if (n_acc == 1) {
@@ -1187,6 +1219,93 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       k_type[0] += (acc_type == THM_ALN_EXONIC);
       k_type[1] += (acc_type == THM_ALN_INTRONIC);
       k_type[2] += (acc_type == THM_ALN_INTERGENIC);
+    } else if (!GS && n_acc > 1 && n_acc <= (uint32_t)KEYCAP) {
+      // ============ retain / filter_overlapping / sort / primary (:177-187), a handful of candidates: lane t holds
+      // candidate t's keys; ranks by comparing against every other candidate through readlane, no memory traffic ======
+      wsync(c);
+      CandKey k;
+      k.ystart = k.yend = 0;
+      k.score = 0;
+      k.name_rank = k.bytes = k.strand_type = 0;
+      if ((uint32_t)lane < n_acc) k = c.ck[lane];
+      const uint32_t my_strand = k.strand_type & 0xffu;
+      // retain(score >= max - range): the survivors keep their order (= lane order)
+      const bool keep = (uint32_t)lane < n_acc && k.score >= max_aln_score - range;
+      const unsigned long long mk = __ballot(keep);
+      const uint32_t m = (uint32_t)__popcll(mk);
+      auto rl64 = [](uint64_t v, int l) {
+        return ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffu), l);
+      };
+      int res_ci = 0;  // lane s: index of the s-th surviving candidate of the sweep
+      if (m == 1) {
+        nres = 1;
+        res_ci = (int)__builtin_ctzll(mk);
+      } else if (m > 1) {
+        // stable sort by (ref_name, strand, ystart) (:322-327): rank among the survivors
+        uint32_t r1 = 0;
+        for (unsigned long long w = mk; w; w &= w - 1ull) {
+          const int u = (int)__builtin_ctzll(w);
+          const uint32_t ur = (uint32_t)__builtin_amdgcn_readlane((int)k.name_rank, u);
+          const uint32_t us = (uint32_t)__builtin_amdgcn_readlane((int)my_strand, u);
+          const uint64_t uy = rl64(k.ystart, u);
+          bool less;
+          if (ur != k.name_rank)
+            less = ur < k.name_rank;
+          else if (us != my_strand)
+            less = us < my_strand;
+          else if (uy != k.ystart)
+            less = uy < k.ystart;
+          else
+            less = u < lane;
+          r1 += less ? 1u : 0u;
+        }
+        // sweep (:329-346)
+        uint64_t max_end = 0, l_yend = 0;
+        uint32_t l_rank = 0, l_strand = 0;
+        int l_score = 0;
+        for (uint32_t sidx = 0; sidx < m; sidx++) {
+          const int ci = (int)__builtin_ctzll(__ballot(keep && r1 == sidx));
+          const uint64_t a_ystart = rl64(k.ystart, ci), a_yend = rl64(k.yend, ci);
+          const uint32_t a_rank = (uint32_t)__builtin_amdgcn_readlane((int)k.name_rank, ci);
+          const uint32_t a_strand = (uint32_t)__builtin_amdgcn_readlane((int)my_strand, ci);
+          const int a_score = __builtin_amdgcn_readlane(k.score, ci);
+          if (nres == 0 || a_ystart >= max_end || a_rank != l_rank || a_strand != l_strand) {
+            max_end = a_yend;
+            if ((uint32_t)lane == nres) res_ci = ci;
+            nres++;
+            l_rank = a_rank;
+            l_strand = a_strand;
+            l_score = a_score;
+            l_yend = a_yend;
+          } else {
+            if (a_score > l_score) {
+              if ((uint32_t)lane == nres - 1) res_ci = ci;
+              l_score = a_score;
+              l_yend = a_yend;
+            }
+            max_end = max(max_end, l_yend);
+          }
+        }
+      }
+      // stable sort by -score (:183); order[] is what compact_kernel follows
+      const bool mine = (uint32_t)lane < nres;
+      const int my_sc = __shfl(k.score, res_ci);
+      uint32_t r2 = 0;
+      for (uint32_t u = 0; u < nres; u++) {
+        const int su = __builtin_amdgcn_readlane(my_sc, (int)u);
+        r2 += (su > my_sc || (su == my_sc && (int)u < lane)) ? 1u : 0u;
+      }
+      if (mine) order[r2] = (uint32_t)res_ci;
+      const uint32_t my_bytes = (uint32_t)__shfl((int)k.bytes, res_ci);
+      // (the shuffles run with every lane active: ds_bpermute returns 0 for a source lane that is masked off)
+      const uint32_t my_st = (uint32_t)__shfl((int)k.strand_type, res_ci);
+      const int ty = mine ? (int)(my_st >> 8) : -1;
+      unsigned long long ob = mine ? (unsigned long long)my_bytes : 0ull;
+      for (int o = 32; o > 0; o >>= 1) ob += __shfl_xor(ob, o);
+      opb = ob;
+      k_type[0] += (unsigned)__popcll(__ballot(ty == THM_ALN_EXONIC));
+      k_type[1] += (unsigned)__popcll(__ballot(ty == THM_ALN_INTRONIC));
+      k_type[2] += (unsigned)__popcll(__ballot(ty == THM_ALN_INTERGENIC));
     } else if (n_acc > 1) {
       __threadfence_block();
     // ============ retain / filter_overlapping / sort / primary (:177-187) ============
@@ -1291,10 +1410,23 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       }
       for (int o = 32; o > 0; o >>= 1) opb += __shfl_xor(opb, o);
     }
+#ifdef THM_PROF_FINAL
+    const unsigned long long tf2 = __builtin_amdgcn_s_memtime();
+#endif
     if (lane == 0) {
       p.read_n_alns[idx] = nres;
       p.read_op_bytes[idx] = opb;
     }
+#ifdef THM_PROF_FINAL
+    {
+      const unsigned long long tf3 = __builtin_amdgcn_s_memtime();
+      c.prof_cols[3] += tf1 - tf0;
+      c.prof_cols[4] += tf2 - tf1;
+      c.prof_cols[5] += tf3 - tf2;
+      c.prof_cols[1] += (n_acc > 1) ? 1 : 0;
+      c.prof_cols[2] += 1;
+    }
+#endif
     PROF_MARK(c, PS_FINAL);
     k_reads++;
     if (nres)
@@ -1400,7 +1532,7 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
 
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
   const dev::ExtCaps k = dev::ext_caps(max_read_len, max_bw);
-  const uint32_t per_wave = k.lcap + 2u * k.wcap + k.trb + 3u * k.opcap + 8u * FAST_MAX_YCLIPS;
+  const uint32_t per_wave = k.lcap + 2u * k.wcap + k.trb + 3u * k.opcap + 8u * FAST_MAX_YCLIPS + (uint32_t)(dev::KEYCAP * sizeof(dev::CandKey));
   (void)cpl;
   return 4 * (size_t)per_wave;
 }
@@ -1426,12 +1558,11 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
-  // register budget: MINW waves per SIMD.  Measured on the 32-bit-coordinate kernels: 8 for the one-cell-per-lane
-  // kernel (64 VGPRs plus spilled ones), 6 for the two-cell-per-lane kernel (80 VGPRs plus spilled ones; with the
-  // wide-band trace in global memory its LDS footprint admits 8 workgroups per CU for 91 bp reads), 4 for wider
-  // bands.  The spilled registers cost scratch traffic and buy 8 % more throughput than 5 waves; tuning knob
-  // THM_EXT_MINW = 4 | 5 | 6 | 8 for the one- and two-cell kernels.  The 64-bit-coordinate kernels carry
-  // more live state per hit and run at 4 waves per SIMD.
+  // register budget: MINW waves per SIMD.  Measured on the 32-bit-coordinate kernels (round 2, benchmark workload,
+  // same box): one cell per lane 3.60 ms at 6 waves against 3.90 at 8 (560 bytes per lane of spills) and 3.96 at 4;
+  // two cells per lane 3.97 ms at 6 (80 VGPRs, 128 bytes of spills) against 4.02 at 5, 4.23 at 8, 4.64 at 4; wider
+  // bands run at 4.  Tuning knob THM_EXT_MINW = 4 | 5 | 6 | 8 for the one- and two-cell kernels.  The
+  // 64-bit-coordinate kernels carry more live state per hit and run at 4 waves per SIMD.
   static const int minw_env = [] {
     const char* e = getenv("THM_EXT_MINW");
     const int v = e ? atoi(e) : 0;
@@ -1447,7 +1578,7 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
       default: return hipErrorInvalidValue;
     }
   } else {
-    const int minw = minw_env ? minw_env : (cpl == 1 ? 8 : (cpl == 2 ? 6 : 4));
+    const int minw = minw_env ? minw_env : (cpl <= 2 ? 6 : 4);
     switch (cpl) {
       case 1:
         if (minw == 4) return go(dev::extend_kernel<C, 1, 4>);
