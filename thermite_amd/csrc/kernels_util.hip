@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void calib_gather_kernel(const uint8_t* table,
     const uint4 v = *(const uint4*)(table + o);
     acc = v.x ^ v.y ^ v.z ^ v.w;
   }
-  if (acc == 0x9e3779b97f4a7c15ull) *sink = acc;  // keeps the loads alive
+  if (acc == 0x7f4a7c15ull) *sink = acc;  // keeps the loads alive (a value all three patterns can produce)
 }
 
 }  // namespace dev

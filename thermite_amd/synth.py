@@ -154,3 +154,46 @@ def synth_reference(length=CHR21_LEN, n_genes=None, seed=SEED, name="chr21syn", 
     seq = synth_contig(rng, length, n_lead, copies_per_family=max(3, int(250 * scale)), n_segdups=max(2, int(40 * scale)))
     genes, txs = synth_annotation(rng, name, length, n_lead + 500, n_genes)
     return refdata.build_tables([(name, seq)], genes, txs)
+
+
+def heavy_repeat_reference(length=3_000_000, copies=3000, unit_len=300, divergence=0.02, n_genes=24, seed=SEED, name="heavysyn"):
+    """A reference with one Alu-like family: `copies` copies of a `unit_len`-mer, each diverged from the consensus by
+    `divergence` per base (either strand).  Two copies share a given 25-mer with probability about
+    (1 - divergence)^50, so a read from one copy that carries a sequencing error has SMEMs of 20-60 bases
+    with hundreds to thousands of occurrences (the reference extends every one of them,
+    src/index.rs:236-248, src/aligner.rs:143-145).  Returns (tables, start positions of the copies on the contig)."""
+    rng = _rng(seed, 7)
+    seq = _ACGT[rng.integers(0, 4, length, dtype=np.uint8)]
+    cons = _ACGT[rng.integers(0, 4, unit_len, dtype=np.uint8)]
+    slot = (length - 2000) // copies
+    if slot < unit_len + 10:
+        raise ValueError("reference too short for %d copies of %d bases" % (copies, unit_len))
+    pos = np.zeros(copies, np.int64)
+    for c in range(copies):
+        u = cons.copy()
+        m = rng.random(unit_len) < divergence
+        u[m] = _ACGT[rng.integers(0, 4, int(m.sum()), dtype=np.uint8)]
+        if rng.random() < 0.5:
+            u = refdata.revcomp(u)
+        p = 1000 + c * slot + int(rng.integers(0, slot - unit_len))
+        seq[p: p + unit_len] = u
+        pos[c] = p
+    genes, txs = synth_annotation(rng, name, length, 500, n_genes)
+    return refdata.build_tables([(name, seq)], genes, txs), pos
+
+
+def reads_from_positions(tables, starts, read_len=91, sub_rate=0.01, seed=SEED, stream=0, flip_prob=0.5):
+    """One read per start position on the first contig's forward strand (substitutions only, strand flip)."""
+    rng = _rng(seed, stream)
+    fwd = tables["text"][: int(tables["refs"][0]["len"])]
+    starts = np.asarray(starts, np.int64)
+    reads = fwd[starts[:, None] + np.arange(read_len, dtype=np.int64)[None, :]].copy()
+    m = rng.random(reads.shape) < sub_rate
+    code = np.full(256, 255, np.uint8)
+    code[_ACGT] = np.arange(4, dtype=np.uint8)
+    c = code[reads[m]]
+    reads[m] = np.where(c < 4, _ACGT[(c + rng.integers(1, 4, c.shape[0]).astype(np.uint8)) % 4], reads[m])
+    flip = rng.random(len(starts)) < flip_prob
+    reads[flip] = refdata._COMP[reads[flip][:, ::-1]]
+    n = len(starts)
+    return np.ascontiguousarray(reads.reshape(-1)), (np.arange(n + 1, dtype=np.uint64) * np.uint64(read_len)).astype("<u8")

@@ -88,28 +88,33 @@ if s1:
         d = {n: round(v, 1) for n, v in c.items()}
         wc = c.get("SQ_WAVE_CYCLES", 0)
         if wc:
-            # per-wave view: share of a resident wave's cycles in which it issues a VALU instruction / anything, or is parked
-            d["valu_issue_share_of_wave_cycles"] = round(4 * c.get("SQ_ACTIVE_INST_VALU", 0) / wc, 4)
-            d["any_issue_share_of_wave_cycles"] = round(4 * c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 4)
-            d["wait_any_share_of_wave_cycles"] = round(4 * c.get("SQ_WAIT_ANY", 0) / wc, 4)
-            d["wait_inst_share_of_wave_cycles"] = round(4 * c.get("SQ_WAIT_INST_ANY", 0) / wc, 4)
-        bc = c.get("SQ_BUSY_CYCLES", 0)
-        if bc:
-            # SIMD view: VALU-issue cycles per busy SQ cycle (an upper bound of 1 per SIMD would need 4 per CU)
-            d["valu_active_per_busy_cycle"] = round(c.get("SQ_ACTIVE_INST_VALU", 0) / bc, 4)
+            # per-wave view (all four counters in the same unit; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES,
+            # MI355X_MICROARCH.md): share of a resident wave's time in which it issues a VALU instruction / any
+            # instruction, waits to issue, or is parked at s_waitcnt
+            d["valu_issue_share_of_wave_cycles"] = round(c.get("SQ_ACTIVE_INST_VALU", 0) / wc, 4)
+            d["any_issue_share_of_wave_cycles"] = round(c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 4)
+            d["wait_any_share_of_wave_cycles"] = round(c.get("SQ_WAIT_ANY", 0) / wc, 4)
+            d["wait_inst_share_of_wave_cycles"] = round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 4)
         if c.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 4)
         summ[k] = d
     json.dump(summ, open(os.path.join(dst, "sq_counters_bench%s.json" % suffix), "w"), indent=1)
     e = max((v for k, v in summ.items() if k.startswith("extend_kernel")), key=lambda v: v.get("SQ_INSTS_VALU", 0))
+    # SIMD view: a SIMD issues one VALU instruction at a time; with W waves resident per SIMD its vector ALU is busy
+    # W x (per-wave VALU share) of the time.  W = 6 for the two-cells-per-lane extend kernel (80 VGPRs).
+    W = 6
     sq = {"round": 2, "reads_per_gpu": n_reads, "ref_len": 46709983, "opts": "ci",
-          "extend_valu_busy_frac": e.get("valu_issue_share_of_wave_cycles"),
+          "extend_valu_busy_frac": round(min(1.0, W * e.get("valu_issue_share_of_wave_cycles", 0)), 4),
+          "extend_waves_per_simd": W,
+          "extend_valu_share_per_wave": e.get("valu_issue_share_of_wave_cycles"),
+          "extend_wait_inst_share": e.get("wait_inst_share_of_wave_cycles"),
           "extend_valu_insts_per_read": round(e.get("SQ_INSTS_VALU", 0) / n_reads, 1),
           "extend_wait_any_share": e.get("wait_any_share_of_wave_cycles"),
           "source": "profiles/r02/sq_counters_bench%s.json (rocprofv3 --pmc SQ_*; valu_busy = 4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)" % suffix}
     json.dump(sq, open(os.path.join(ROOT, "profiles", "sq_counters.json"), "w"), indent=1)
     for k, d in summ.items():
-        print(k, {n: d[n] for n in d if "share" in n or "per_busy" in n}, "VALU/launch", d.get("SQ_INSTS_VALU"))
+        if "rocclr" not in k:
+            print(k, {n: d[n] for n in d if "share" in n}, "VALU/launch", d.get("SQ_INSTS_VALU"))
 
 cal = counters("calib")
 cj = os.path.join(base, "calib.json")
