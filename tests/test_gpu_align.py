@@ -347,3 +347,35 @@ def test_reads_beyond_every_class_get_a_status(chrm):
     assert np.array_equal(np.delete(np.diff(g.offsets.astype(np.int64)), 77), np.diff(ref.offsets.astype(np.int64)))
     assert np.array_equal(g.alns["score"], ref.alns["score"]) and np.array_equal(g.ops, ref.ops)
     a.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# reads with hundreds to thousands of seed hits (no cap on seed occurrences, src/index.rs:236-248,
+# src/aligner.rs:143-175): a workgroup per read, speculative chunks of hits (kernels_extend.hip, TEAM)
+@pytest.fixture(params=[False, True], ids=["c32", "c64"])
+def heavy(request):
+    def make():
+        t, pos = synth.heavy_repeat_reference(length=6_000_000, copies=8000, divergence=0.01)
+        t["_copy_pos"] = pos
+        return t
+    return _world("heavy", make, request.param)
+
+
+def test_heavy_reads_thousands_of_hits(heavy):
+    rng = np.random.default_rng(3)
+    pos = heavy.t["_copy_pos"]
+    starts = pos[rng.integers(0, len(pos), 90)] + rng.integers(0, 300 - 91, 90)
+    hb, ho = synth.reads_from_positions(heavy.t, starts, 91, sub_rate=0.02, stream=12)
+    lb, lo, _ = synth.simulate_reads(heavy.t, 3000, 91, sub_rate=0.01, indel_rate=0.001, intronic_frac=0.3, stream=13)
+    reads = [lb[lo[i]: lo[i + 1]] for i in range(3000)]
+    for i in range(90):
+        reads.insert(int(rng.integers(0, len(reads) + 1)), hb[ho[i]: ho[i + 1]])
+    b2, o2 = refdata.pack_reads(reads)
+    a = heavy.aligner(capi.CI_OPTS)
+    mo, _ = a.smems_batch(b2, o2, 20)
+    hits = np.diff(mo.astype(np.int64))
+    assert hits.max() >= 2000 and (hits >= 256).sum() >= 3  # the team path is taken
+    a.close()
+    check_align(heavy, b2, o2, capi.CI_OPTS)
+    check_align(heavy, b2, o2, capi.DEFAULT_OPTS)
+    check_align(heavy, b2, o2, dict(capi.CI_OPTS, multimap_score_range=6, min_seed_len=16))

@@ -105,7 +105,7 @@ struct thm_aligner {
   bool uploaded = false;
   // seeds
   DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp, s_ms_end, s_ms_lo, s_ms_hi, s_work_reads, s_work_long, s_work_cells,
-      s_work_counts, s_sel_scratch, s_heavy, s_slow;
+      s_work_counts, s_sel_scratch, s_heavy, s_slow, s_team;
   uint64_t smem_cap = 0;
   // extension
   DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace, e_slow, e_recs;

@@ -570,6 +570,8 @@ __device__ unsigned long long emit_alignment(W& c, const PP& p, const uint8_t* p
   return off;
 }
 
+constexpr int TEAM_MAX_CHUNKS = 4096;  // chunks of <= 64 hits a team keeps book of (reads beyond that stay with the sequential path)
+
 // per-wave buffer sizes, shared by the kernel's carve-up and the host's sizing functions
 struct ExtCaps {
   uint32_t lcap, wcap, ycols, trb, opcap;
@@ -619,10 +621,28 @@ __host__ __device__ inline SlowLayout slow_layout(uint32_t max_read_len, uint32_
 // C: coordinate width.  CPL: band slots per lane of the register-resident DP (1..4), or 0 for the any-width
 // kernel (band in tiles, wave-private buffers in global memory): the slow path for reads whose band or length
 // exceeds what LDS and registers hold.  MINW: waves per SIMD the register budget is set for.
-template <class C, int CPL, int MINW>
-__global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by_value) {
+//
+// TEAM > 0: the kernel for reads with very many seed hits (plan_kernel lists them).  A workgroup of
+// TEAM wavefronts works on ONE read at a time.  The hits of a read must be taken in order because band, X-drop
+// and best score are carried from hit to hit (src/aligner.rs:143-175) -- but they change only when a hit beats the
+// best score so far, which happens a handful of times per read, early.  So the hits are cut into the chunks of
+// up to 64 the loop below walks anyway, and in every round wave w takes chunk (base + w), starting from the state
+// that is known to hold at chunk `base` -- speculating that the chunks before its own leave the state alone.
+// After the round the chunks up to and including the first one that changed the state are valid (each of them did
+// start from the true state); their candidates and counters are kept, the state moves on, and the chunks behind
+// them are redone in the next round.  Exact: every hit that is kept was extended under exactly the band, X-drop
+// and threshold the sequential loop would have used.  Speed-up on a read whose state has settled: TEAM-fold.
+template <class C, int CPL, int MINW, int TEAM = 0>
+__global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) void extend_kernel(ExtendParamsT<C> p_by_value) {
   typedef typename CoordTraits<C>::S S;
   constexpr bool GS = (CPL == 0);
+  constexpr bool TM = TEAM > 0;
+  constexpr int TW = TM ? TEAM : 1;
+  // team state (LDS, unused when TEAM == 0)
+  __shared__ int t_res[TW][8];        // per wave and round: accepted candidates, state changed?, band, X-drop, best score, per-read fault bits
+  __shared__ int t_state[4];          // the state in force at chunk t_ctl[1]: band, X-drop, best score
+  __shared__ unsigned t_ctl[4];       // [0] list slot of the read, [1] first chunk of the round, [2] accepted so far, [3] per-read fault bits
+  __shared__ unsigned short t_nacc[TM ? TEAM_MAX_CHUNKS : 1];  // accepted candidates per finished chunk
   typedef WctxT<GS> Wctx;
   // The parameter block (about 80 dwords) is read from the kernel-argument segment where it is
   // needed (scalar loads, THM_KARG_QUAL = volatile keeps them at their use sites) instead of being
@@ -714,19 +734,35 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
   // the end of the batch and the whole grid would wait for them (a quarter of the kernel's time
   // on the benchmark workload).  The any-width kernel works from its list alone.
   bool heavy_phase = true;
-  const unsigned n_heavy = (unsigned)uload(p.heavy_count);
+  // (see ExtendParamsT::team) the team list is the team kernel's while it is short, else the wave-per-read kernel's
+  const unsigned n_team_all = (GS || p.team_count == nullptr) ? 0u : (unsigned)uload(p.team_count);
+  const bool team_active = n_team_all <= p.team_limit;
+  const unsigned n_heavy_own = TM ? 0u : (unsigned)uload(p.heavy_count);
+  const unsigned n_heavy = TM ? (team_active ? n_team_all : 0u) : n_heavy_own + ((!GS && !team_active && !list_only) ? n_team_all : 0u);
   const unsigned list_q = (GS ? EXT_NQ + 1 : EXT_NQ) * EXT_QSTRIDE;
   // (Issuing the atomic for the next read while the current one is worked on was tried: the pending return value
   // stays live across the whole hit loop and costs 400 bytes per lane of spills -- three times slower.)
   for (;;) {
     bool from_heavy = false, got = false;
     unsigned idx = 0;
+    if constexpr (TM) {
+      // one read for the whole workgroup
+      if (threadIdx.x == 0) t_ctl[0] = atomicAdd(p.queue + (EXT_NQ + 2) * EXT_QSTRIDE, 1u);
+      __syncthreads();
+      const unsigned g = t_ctl[0];
+      __syncthreads();
+      if (g >= n_heavy) break;
+      idx = (unsigned)uload(&p.team[g]);
+      got = true;
+      from_heavy = true;
+      heavy_phase = false;
+    }
     if (!got && heavy_phase) {
       unsigned g = 0;
       if (lane == 0) g = atomicAdd(p.queue + list_q, 1u);
       g = (unsigned)bcast_first((int)g);
       if (g < n_heavy) {
-        idx = (unsigned)uload(&p.heavy[g]);
+        idx = (g < n_heavy_own) ? (unsigned)uload(&p.heavy[g]) : (unsigned)uload(&p.team[g - n_heavy_own]);
         got = true;
         from_heavy = true;
       } else {
@@ -791,6 +827,38 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
 #ifdef THM_PROF
     c.prof_hit = 0;
 #endif
+    // ---- team bookkeeping (TEAM > 0; see the comment at the kernel's head) ----
+    unsigned t_base = 0, t_total = 0;
+    if constexpr (TM) {
+      if (threadIdx.x == 0) {
+        t_state[0] = band_width;
+        t_state[1] = x_drop;
+        t_state[2] = max_aln_score;
+        t_ctl[1] = 0;
+        t_ctl[2] = 0;
+        t_ctl[3] = 0;
+      }
+      __syncthreads();
+    }
+    for (;;) {  // rounds of the team; a single pass otherwise
+    unsigned cc = 0;            // chunk counter of the walk
+    uint64_t h_start = 0;       // hit ordinal of the chunk's first hit = its first candidate slot
+    const unsigned my_chunk = t_base + (unsigned)wave;
+    int st_bw = 0, st_xd = 0, st_max = 0;
+    unsigned sv_cells = 0, sv_cols = 0, sv_calls = 0, sv_win = 0;
+    if constexpr (TM) {
+      band_width = t_state[0];
+      x_drop = t_state[1];
+      max_aln_score = t_state[2];
+      st_bw = band_width;
+      st_xd = x_drop;
+      st_max = max_aln_score;
+      n_acc = 0;
+      sv_cells = c.cells;
+      sv_cols = c.cols;
+      sv_calls = c.calls;
+      sv_win = c.winbytes;
+    }
     for (uint32_t si = 0; si < n_sm; si++) {
       SmemT<C> sm;
       if (si == 0) {  // the first SMEM travels in the read's record
@@ -805,6 +873,14 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       C rr = sm.hi;
       while (rr > sm.lo) {
         const uint32_t chunk = (uint32_t)min((C)64, (C)(rr - sm.lo));
+        if (TM && cc != my_chunk) {  // somebody else's chunk (or one that is finished)
+          rr -= chunk;
+          h_start += chunk;
+          cc++;
+          continue;
+        }
+        Cand* const cslot = TM ? cands + h_start : cands;  // a team's chunk writes its candidates from its first hit's slot
+        const uint64_t slot_cap = TM ? (uint64_t)chunk : n_hits_cap;
         C my_sa = 0;
         if (si == 0 && rr == sm.hi && chunk == 1)
           my_sa = rec.sa0;  // ... and so does its first (here: only) occurrence
@@ -1118,7 +1194,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
             const unsigned long long off = emit_alignment(c, p, g_path, g_n, xs_, xe_, rev, g_ny, nb);
             unsigned long long toff2 = 0;
             if (exonic) toff2 = emit_alignment(c, p, best_buf, best.nops, best.xstart, best.xend, false, 0, tnb);
-            if (n_acc >= n_hits_cap) {
+            if (n_acc >= slot_cap) {
               c.fault |= FAULT_INTERNAL;
             } else if (lane == 0) {
               Cand cd;
@@ -1152,8 +1228,8 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
                 cd.tx_xstart = (uint32_t)best.xstart;
                 cd.tx_xend = (uint32_t)best.xend;
               }
-              cands[n_acc] = cd;
-              if (!GS && n_acc < (uint32_t)KEYCAP) {
+              cslot[n_acc] = cd;
+              if (!GS && !TM && n_acc < (uint32_t)KEYCAP) {
                 CandKey k;
                 k.ystart = ch0;
                 k.yend = ch1;
@@ -1179,7 +1255,70 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
 #endif
         }
         rr -= chunk;
+        h_start += chunk;
+        cc++;
       }
+    }
+    if constexpr (!TM) {
+      break;
+    } else {
+      // ---- end of a round: which chunks are valid? ----
+      t_total = cc;
+      if (t_total > (unsigned)TEAM_MAX_CHUNKS) c.fault |= FAULT_INTERNAL;  // plan_kernel keeps such reads away from the team
+      const bool active = my_chunk < t_total;
+      const bool changed = active && (band_width != st_bw || x_drop != st_xd || max_aln_score != st_max);
+      if (lane == 0) {
+        t_res[wave][0] = active ? (int)n_acc : 0;
+        t_res[wave][1] = changed ? 1 : 0;
+        t_res[wave][2] = band_width;
+        t_res[wave][3] = x_drop;
+        t_res[wave][4] = max_aln_score;
+        t_res[wave][5] = active ? (c.fault & (FAULT_RETRY | FAULT_CONTRACT)) : 0;
+      }
+      __syncthreads();
+      int valid = (int)min((unsigned)TEAM, t_total > t_base ? t_total - t_base : 0u);
+      int wstar = -1;
+      for (int w2 = 0; w2 < valid; w2++)
+        if (t_res[w2][1]) {
+          wstar = w2;
+          break;
+        }
+      if (wstar >= 0) valid = wstar + 1;
+      c.fault &= ~(FAULT_RETRY | FAULT_CONTRACT);  // per-read outcomes travel through t_ctl[3] (valid chunks only)
+      if (wave >= valid) {  // speculation failed (or no chunk): this round's work of the wave does not count
+        c.cells = sv_cells;
+        c.cols = sv_cols;
+        c.calls = sv_calls;
+        c.winbytes = sv_win;
+      }
+      if (threadIdx.x == 0) {
+        unsigned acc = 0, fl = 0;
+        for (int w2 = 0; w2 < valid; w2++) {
+          if (t_base + (unsigned)w2 < (unsigned)TEAM_MAX_CHUNKS) t_nacc[t_base + w2] = (unsigned short)t_res[w2][0];
+          acc += (unsigned)t_res[w2][0];
+          fl |= (unsigned)t_res[w2][5];
+        }
+        if (wstar >= 0) {
+          t_state[0] = t_res[wstar][2];
+          t_state[1] = t_res[wstar][3];
+          t_state[2] = t_res[wstar][4];
+        }
+        t_ctl[1] = t_base + (unsigned)valid;
+        t_ctl[2] += acc;
+        t_ctl[3] |= fl;
+      }
+      __syncthreads();
+      t_base = t_ctl[1];
+      if (t_base >= t_total) break;
+    }
+    }  // rounds
+    // team: the whole workgroup goes through the final section (the two rank sorts are shared out over the waves);
+    // everything that has a side effect or keeps the read's books is wave 0's
+    const bool lead = !TM || wave == 0;
+    if constexpr (TM) {
+      n_acc = t_ctl[2];
+      max_aln_score = t_state[2];
+      c.fault |= (int)t_ctl[3];
     }
     PROF_MARK(c, PS_OTHER);
 #ifdef THM_PROF_FINAL
@@ -1189,7 +1328,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
     if (c.fault & FAULT_RETRY) {
       // more introns in one alignment than this kernel's marker list holds: the any-width kernel redoes the read
       c.fault &= ~(FAULT_RETRY | FAULT_CONTRACT);
-      if (lane == 0) {
+      if (lead && lane == 0) {
         const unsigned long long slot = atomicAdd(p.retry_count, 1ull);
         p.retry[slot] = idx;
       }
@@ -1200,7 +1339,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       // a condition that panics in the reference (lift_mem_to_tx / lift_tx_to_gx): no alignments, per-read status
       c.fault &= ~FAULT_CONTRACT;
       n_acc = 0;
-      if (lane == 0) {
+      if (lead && lane == 0) {
         p.read_status[idx] = THM_ERR_OUT_OF_CONTRACT;
         atomicAdd(p.n_contract, 1ull);
       }
@@ -1211,7 +1350,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
 #endif
     uint32_t nres = 0;
     unsigned long long opb = 0;
-    if (n_acc == 1) {
+    if (!TM && n_acc == 1) {
       // the common case: one candidate, which by construction passes retain() (its score is the maximum)
       nres = 1;
       if (lane == 0) order[0] = 0;
@@ -1219,7 +1358,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       k_type[0] += (acc_type == THM_ALN_EXONIC);
       k_type[1] += (acc_type == THM_ALN_INTRONIC);
       k_type[2] += (acc_type == THM_ALN_INTERGENIC);
-    } else if (!GS && n_acc > 1 && n_acc <= (uint32_t)KEYCAP) {
+    } else if (!GS && !TM && n_acc > 1 && n_acc <= (uint32_t)KEYCAP) {
       // ============ retain / filter_overlapping / sort / primary (:177-187), a handful of candidates: lane t holds
       // candidate t's keys; ranks by comparing against every other candidate through readlane, no memory traffic ======
       wsync(c);
@@ -1306,13 +1445,55 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       k_type[0] += (unsigned)__popcll(__ballot(ty == THM_ALN_EXONIC));
       k_type[1] += (unsigned)__popcll(__ballot(ty == THM_ALN_INTRONIC));
       k_type[2] += (unsigned)__popcll(__ballot(ty == THM_ALN_INTERGENIC));
-    } else if (n_acc > 1) {
-      __threadfence_block();
+    } else if (TM ? n_acc >= 1 : n_acc > 1) {
+      // between the steps: every store visible to every wave that reads it (a workgroup barrier for a team)
+      auto step = [&] {
+        if constexpr (TM)
+          __syncthreads();
+        else
+          __threadfence_block();
+      };
+      const uint32_t t0_first = TM ? (uint32_t)wave * 64u : 0u, t0_step = TM ? 64u * (uint32_t)TW : 64u;
+      step();
     // ============ retain / filter_overlapping / sort / primary (:177-187) ============
     uint32_t* la = order;               // list A
     uint32_t* lb = order + n_hits_cap;  // list B
     uint32_t m = 0;
     // retain(score >= max - range), keeps order
+    if constexpr (TM) {
+      // the candidates of chunk cc sit in the slots from its first hit on, t_nacc[cc] of them
+      if (lead) {
+      unsigned cc2 = 0;
+      uint64_t hs = 0;
+      for (uint32_t si = 0; si < n_sm; si++) {
+        C lo2, hi2;
+        if (si == 0) {
+          lo2 = rec.lo0;
+          hi2 = rec.hi0;
+        } else {
+          const SmemT<C> sm2 = uload(&p.smems[s0 + si]);
+          lo2 = sm2.lo;
+          hi2 = sm2.hi;
+        }
+        C left = hi2 - lo2;
+        while (left > 0) {
+          const uint32_t chunk = (uint32_t)min((C)64, left);
+          const uint32_t na = cc2 < (unsigned)TEAM_MAX_CHUNKS ? (uint32_t)t_nacc[cc2] : 0u;
+          const uint32_t slot = (uint32_t)hs + (uint32_t)lane;
+          const bool keep = (uint32_t)lane < na && (cands[slot].score >= max_aln_score - range);
+          const unsigned long long mk = __ballot(keep);
+          if (keep) la[m + __popcll(mk & ((1ull << lane) - 1ull))] = slot;
+          m += (uint32_t)__popcll(mk);
+          left -= chunk;
+          hs += chunk;
+          cc2++;
+        }
+      }
+      if (lane == 0) t_ctl[1] = m;
+      }
+      __syncthreads();
+      m = t_ctl[1];
+    } else {
     #pragma unroll 1
     for (uint32_t t0 = 0; t0 < n_acc; t0 += 64) {
       const uint32_t t = t0 + lane;
@@ -1321,13 +1502,14 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
       if (keep) la[m + __popcll(mk & ((1ull << lane) - 1ull))] = t;
       m += (uint32_t)__popcll(mk);
     }
-    __threadfence_block();
+    }
+    step();
     if (m == 1) {
       nres = 1;
     } else if (m > 1) {
       // stable sort by (ref_name, strand, ystart) (:322-327): rank sort la -> lb
       #pragma unroll 1
-      for (uint32_t t0 = 0; t0 < m; t0 += 64) {
+      for (uint32_t t0 = t0_first; t0 < m; t0 += t0_step) {
         const uint32_t t = t0 + lane;
         if (t < m) {
           const Cand a = cands[la[t]];
@@ -1348,8 +1530,9 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
           lb[rank] = la[t];
         }
       }
-      __threadfence_block();
+      step();
       // sweep (:329-346): result into la
+      if (lead) {
       uint64_t max_end = 0;
       uint32_t l_rank = 0, l_strand = 0;
       int l_score = 0;
@@ -1374,10 +1557,13 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
           max_end = max(max_end, l_yend);
         }
       }
-      __threadfence_block();
+      if (TM && lane == 0) t_ctl[1] = nres;
+      }
+      step();
+      if constexpr (TM) nres = t_ctl[1];
       // stable sort by -score (:183): rank sort la -> lb, then copy back
       #pragma unroll 1
-      for (uint32_t t0 = 0; t0 < nres; t0 += 64) {
+      for (uint32_t t0 = t0_first; t0 < nres; t0 += t0_step) {
         const uint32_t t = t0 + lane;
         if (t < nres) {
           const int sa_ = cands[la[t]].score;
@@ -1389,14 +1575,14 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
           lb[rank] = la[t];
         }
       }
-      __threadfence_block();
+      step();
       #pragma unroll 1
-      for (uint32_t t = lane; t < nres; t += 64) la[t] = lb[t];
-      __threadfence_block();
+      for (uint32_t t = t0_first + lane; t < nres; t += t0_step) la[t] = lb[t];
+      step();
     }
-      // per-read totals
+      // per-read totals (a team: wave 0's)
       #pragma unroll 1
-      for (uint32_t t0 = 0; t0 < nres; t0 += 64) {
+      for (uint32_t t0 = 0; lead && t0 < nres; t0 += 64) {
         const uint32_t t = t0 + (uint32_t)lane;
         int ty = -1;
         if (t < nres) {
@@ -1413,7 +1599,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
 #ifdef THM_PROF_FINAL
     const unsigned long long tf2 = __builtin_amdgcn_s_memtime();
 #endif
-    if (lane == 0) {
+    if (lead && lane == 0) {
       p.read_n_alns[idx] = nres;
       p.read_op_bytes[idx] = opb;
     }
@@ -1428,13 +1614,15 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
     }
 #endif
     PROF_MARK(c, PS_FINAL);
-    k_reads++;
-    if (nres)
-      k_aligned++;
-    else
-      k_unmapped++;
-    k_alns += nres;
-    k_opb += opb;
+    if (lead) {
+      k_reads++;
+      if (nres)
+        k_aligned++;
+      else
+        k_unmapped++;
+      k_alns += nres;
+      k_opb += opb;
+    }
     k_cells += c.cells;
     k_cols += c.cols;
     k_calls += c.calls;
@@ -1452,7 +1640,7 @@ __global__ __launch_bounds__(256, MINW) void extend_kernel(ExtendParamsT<C> p_by
   batch_fault |= c.fault & (FAULT_OPS_POOL | FAULT_INTERNAL);
   if (lane == 0) {
     if (batch_fault) atomicOr(p.fault, batch_fault & (FAULT_OPS_POOL | FAULT_INTERNAL));
-    if (k_reads) {
+    if (k_reads | k_calls | k_cells | k_win) {
       atomicAdd(&p.counters[THM_CNT_READS], k_reads);
       atomicAdd(&p.counters[THM_CNT_ALIGNED], k_aligned);
       atomicAdd(&p.counters[THM_CNT_UNMAPPED], k_unmapped);
@@ -1548,16 +1736,23 @@ size_t extend_slow_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, uint32_
 }
 
 template <class C>
-static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_blocks, hipStream_t s) {
-  const size_t lds = cpl == 0 ? 0 : extend_lds_bytes(p.max_read_len, p.max_bw, cpl);
+static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_blocks, hipStream_t s, bool team) {
+  const size_t lds4 = cpl == 0 ? 0 : extend_lds_bytes(p.max_read_len, p.max_bw, cpl);
+  const size_t lds = team ? lds4 / 4 * TEAM_WAVES : lds4;
+  const unsigned threads = team ? 64u * TEAM_WAVES : 256u;
   auto go = [&](auto kern) -> hipError_t {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(threads), lds, s, p);
     return hipGetLastError();
   };
+  if (team) {
+    if (cpl == 1) return go(dev::extend_kernel<C, 1, 4, TEAM_WAVES>);
+    if (cpl == 2) return go(dev::extend_kernel<C, 2, 4, TEAM_WAVES>);
+    return hipErrorInvalidValue;
+  }
   // register budget: MINW waves per SIMD.  Measured on the 32-bit-coordinate kernels (round 2, benchmark workload,
   // same box): one cell per lane 3.60 ms at 6 waves against 3.90 at 8 (560 bytes per lane of spills) and 3.96 at 4;
   // two cells per lane 3.97 ms at 6 (80 VGPRs, 128 bytes of spills) against 4.02 at 5, 4.23 at 8, 4.64 at 4; wider
@@ -1595,8 +1790,8 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
     }
   }
 }
-hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s) { return launch_extend_t(p, cpl, n_blocks, s); }
-hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s) { return launch_extend_t(p, cpl, n_blocks, s); }
+hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s, bool team) { return launch_extend_t(p, cpl, n_blocks, s, team); }
+hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s, bool team) { return launch_extend_t(p, cpl, n_blocks, s, team); }
 
 hipError_t launch_compact(const CompactParams& p, hipStream_t s) {
   const unsigned blocks = (unsigned)((p.n_reads + 15) / 16);

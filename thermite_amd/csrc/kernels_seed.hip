@@ -755,8 +755,10 @@ __global__ __launch_bounds__(256) void plan_kernel(PlanParams p) {
     p.read_n_alns[r] = 0;
     p.read_op_bytes[r] = 0;
   }
-  block_append(fast && hits >= HEAVY_HITS, r, p.heavy, &p.counts[2]);
+  const bool team = fast && p.team_ok && hits >= TEAM_HITS && hits <= TEAM_MAX_HITS;
+  block_append(fast && !team && hits >= HEAVY_HITS, r, p.heavy, &p.counts[2]);
   block_append(slow, r, p.slow, &p.counts[5]);
+  block_append(team, r, p.team, &p.counts[7]);
 }
 
 // One record per read for the extend kernel (launch.h, ReadRecT): thread per read

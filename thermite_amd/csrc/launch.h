@@ -100,6 +100,8 @@ struct PlanParams {
   uint32_t slow_max_len;  // longer ones up to this length in the any-width kernel; beyond: THM_ERR_UNSUPPORTED
   unsigned long long* heavy;
   unsigned long long* slow;
+  unsigned long long* team;    // reads with >= TEAM_HITS hits (counts[7]) when team_ok
+  uint32_t team_ok;
   unsigned long long* counts;  // work_counts of the seed stage
   int32_t* read_status;
   uint32_t* read_n_alns;       // zeroed for unsupported reads
@@ -176,8 +178,12 @@ struct Cand {
 
 // work counters of the extend kernel: EXT_NQ of them, EXT_QSTRIDE u32 apart (separate cache lines)
 constexpr unsigned EXT_NQ = 8, EXT_QSTRIDE = 64;
-constexpr size_t QUEUE_BYTES = (EXT_NQ + 2) * EXT_QSTRIDE * 4;  // + the counter of the heavy-read list + the one of the slow list
+constexpr size_t QUEUE_BYTES = (EXT_NQ + 3) * EXT_QSTRIDE * 4;  // + the counters of the heavy-read list, the slow list and the team list
 constexpr unsigned HEAVY_HITS = 8;  // reads with at least this many seed hits are scheduled first
+// reads with at least this many hits are worked on by a whole workgroup (extend_kernel, TEAM): speculative chunks of hits
+constexpr unsigned TEAM_HITS = 256;
+constexpr int TEAM_WAVES = 16;
+constexpr unsigned TEAM_MAX_HITS = 200000;  // beyond that the team's per-chunk book does not fit: sequential path
 // intron markers one alignment can carry in the register-resident kernel (LDS); an alignment across more
 // introns sends its read to the any-width kernel, whose marker list is sized by the longest transcript
 constexpr int FAST_MAX_YCLIPS = 64;
@@ -191,6 +197,12 @@ struct ExtendParamsT {
   const ReadRecT<C>* read_recs;   // [n_reads] (pack_reads_kernel)
   const unsigned long long* heavy;        // the list this launch goes through first: reads with >= HEAVY_HITS hits
   const unsigned long long* heavy_count;  // (fast kernel) or the reads of the slow class and the retries (any-width kernel)
+  // reads with >= TEAM_HITS hits.  A workgroup per read pays while such reads are few (the tail of the launch); when
+  // there are more of them than team_limit the wave-per-read kernel takes them as further heavy reads (enough of
+  // them to fill the machine) and the team kernel leaves at once.  Both kernels decide from *team_count.
+  const unsigned long long* team;
+  const unsigned long long* team_count;
+  uint32_t team_limit;
   Cand* cands;
   uint64_t cand_cap;  // entries in cands[] (order[] holds twice as many u32)
   uint32_t* order;  // [total hits] per-read scratch for the final ordering (indices into the read's slice)
@@ -220,8 +232,9 @@ size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
 size_t extend_trace_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
 size_t extend_slow_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, uint32_t mk_cap);  // per wave
 constexpr size_t EXTEND_LDS_LIMIT = 160 * 1024;  // gfx950: one workgroup may take the whole LDS of its CU
-hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s);
-hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s);
+// team = true: the workgroup-per-read variant for reads with very many hits (cpl 1 or 2 only; TEAM_WAVES waves per workgroup)
+hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s, bool team = false);
+hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s, bool team = false);
 
 struct CompactParams {
   uint64_t n_reads;

@@ -215,6 +215,9 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   ep.read_recs = a->e_recs.as<ReadRecT<C>>();
   ep.heavy = a->s_heavy.as<unsigned long long>();
   ep.heavy_count = a->s_work_counts.as<unsigned long long>() + 2;
+  ep.team = a->s_team.as<unsigned long long>();
+  ep.team_count = a->s_work_counts.as<unsigned long long>() + 7;
+  ep.team_limit = 2u * (uint32_t)a->n_cu;
   ep.cands = a->e_cands.as<Cand>();
   ep.cand_cap = a->cand_cap;
   ep.order = a->e_order.as<uint32_t>();
@@ -243,9 +246,17 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   const int cpl = std::max(1, (int)((2 * cls.fast_bw + 1 + 63) / 64));
   const size_t lds = extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl);
   const int ext_blocks = blocks_for(a, n, lds);
-  HIPCHK(a, a->e_trace.ensure((size_t)ext_blocks * 4 * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
+  const bool team_ok = cpl <= 2 && lds / 4 * TEAM_WAVES <= EXTEND_LDS_LIMIT;
+  const size_t trace_waves = std::max<size_t>((size_t)ext_blocks * 4, team_ok ? (size_t)a->n_cu * TEAM_WAVES : 0);
+  HIPCHK(a, a->e_trace.ensure(trace_waves * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
   ep.trace_scratch = a->e_trace.as<unsigned long long>();
   HIPCHK(a, launch_extend(ep, cpl, ext_blocks, s));
+  // reads with very many hits: a workgroup per read (speculative chunks of hits, kernels_extend.hip TEAM)
+  if (team_ok) {
+    ExtendParamsT<C> tp = ep;
+    tp.list_only = 1;
+    HIPCHK(a, launch_extend(tp, cpl, a->n_cu, s, true));
+  }
   // ---- slow class (and the fast kernel's retries) ----
   if (cls.n_slow || retry_possible) {
     const uint32_t sl_len = std::max(cls.slow_len, cls.fast_len), sl_bw = std::max(cls.slow_bw, cls.fast_bw);
@@ -260,6 +271,8 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     ep.list_only = 1;
     ep.heavy = a->s_slow.as<unsigned long long>();
     ep.heavy_count = a->s_work_counts.as<unsigned long long>() + 5;
+    ep.team = nullptr;
+    ep.team_count = nullptr;
     ep.slow_scratch = a->e_slow.as<uint8_t>();
     ep.slow_scratch_per_wave = per_wave;
     HIPCHK(a, launch_extend(ep, 0, blocks, s));
@@ -295,6 +308,7 @@ int enqueue_run(thm_aligner* a) {
   HIPCHK(a, a->o_ops.ensure(a->cand_ops_cap + 64));
   HIPCHK(a, a->s_heavy.ensure((n + 1) * 8));
   HIPCHK(a, a->s_slow.ensure((n + 1) * 8));
+  HIPCHK(a, a->s_team.ensure((n + 1) * 8));
   HIPCHK(a, hipMemsetAsync(a->d_queue.p, 0, thm::QUEUE_BYTES, s));
 
   // length classes for the current options; lists for the extend stage
@@ -312,6 +326,11 @@ int enqueue_run(thm_aligner* a) {
   pp.slow_max_len = cls.slow_max;
   pp.heavy = a->s_heavy.as<unsigned long long>();
   pp.slow = a->s_slow.as<unsigned long long>();
+  pp.team = a->s_team.as<unsigned long long>();
+  {
+    const int cpl_f = std::max(1, (int)((2 * cls.fast_bw + 1 + 63) / 64));
+    pp.team_ok = (cpl_f <= 2 && extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl_f) / 4 * TEAM_WAVES <= EXTEND_LDS_LIMIT) ? 1u : 0u;
+  }
   pp.counts = a->s_work_counts.as<unsigned long long>();
   pp.read_status = a->r_status.as<int32_t>();
   pp.read_n_alns = a->e_nalns.as<uint32_t>();

@@ -11,10 +11,17 @@ from oracle import pyoracle as orc
 from gpu_common import assert_batch_equal
 
 n_heavy = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-t, pos = synth.heavy_repeat_reference()
+which = sys.argv[2] if len(sys.argv) > 2 else "moderate"
+if which == "extreme":  # 8 000 near-identical copies: error-free reads have thousands of exact hits, all accepted
+    t, pos = synth.heavy_repeat_reference(length=6_000_000, copies=8000, divergence=0.01)
+else:
+    t, pos = synth.heavy_repeat_reference()
+print("reference:", which, "repeat family of", len(pos), "copies")
 ix = capi.Index(t)
 rng = np.random.default_rng(3)
-light_b, light_o, _ = synth.simulate_reads(t, 200000, 91, sub_rate=0.01, indel_rate=0.001, stream=11)
+n_light = 200000 if which != "extreme" else 2000
+light_b, light_o, _ = synth.simulate_reads(t, n_light, 91, sub_rate=0.01, indel_rate=0.001, stream=11)
+lh = None
 starts = pos[rng.integers(0, len(pos), n_heavy)] + rng.integers(0, 300 - 91, n_heavy)
 heavy_b, heavy_o = synth.reads_from_positions(t, starts, 91, sub_rate=0.02, stream=12)
 a = capi.Aligner(ix, capi.CI_OPTS)
@@ -33,7 +40,7 @@ def timed(b, o, label):
     return a.fetch()
 
 
-timed(light_b, light_o, "200 000 ordinary reads")
+timed(light_b, light_o, "%d ordinary reads" % n_light)
 both_b = np.concatenate([light_b, heavy_b])
 both_o = np.concatenate([light_o, heavy_o[1:] + light_o[-1]]).astype("<u8")
 g = timed(both_b, both_o, "the same + %d heavy reads" % n_heavy)
