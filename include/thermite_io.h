@@ -139,6 +139,13 @@ typedef struct thm_run_stats {
  * format+write) over batches of `batch_reads` reads (0 = 250 000). */
 int32_t thm_align_files(thm_aligner* a, const char* const* fastq_paths, uint32_t n_paths, const char* output_path,
                         int32_t format, uint64_t batch_reads, uint32_t n_threads, thm_run_stats* stats);
+/* The same over several aligners -- one per GPU of the node, all over one index (the shape of ThermiteAligner: Clone +
+ * Send over Arc<Index>, src/wrapper.rs:20-27): batches are dealt to the aligners in input order, each aligner is
+ * driven by its own host thread, parsing runs on several threads, and the records still leave in input order
+ * (src/aligner.rs:54-115).  thm_align_files is this call with one aligner. */
+int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t n_aligners, const char* const* fastq_paths, uint32_t n_paths,
+                              const char* output_path, int32_t format, uint64_t batch_reads, uint32_t n_threads,
+                              thm_run_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,15 @@ def test_chrM_fastq_to_sam_matches_oracle(data_dir, tmp_path, opts_name):
             assert got == want, key
             assert st["n_output_bytes"] == len(want)
         assert st["n_reads"] == n and st["n_aligned_reads"] == int(res.counters[1])
+    # several aligners (one per GPU on a multi-GPU node; here three handles on the one device): the batches are dealt
+    # over them, the records still leave in input order
+    more = [capi.Aligner(a.index, opts) for _ in range(2)]
+    out = tmp_path / "multi.sam"
+    st = capi.align_files([a] + more, [p1, p2], out, capi.FMT_SAM, batch_reads=311, n_threads=6)
+    assert open(out, "rb").read() == ow.sam_header(t) + ow.format_batch(t, names, seqs, quals, res, "sam")
+    assert st["n_reads"] == n and st["n_batches"] >= 16
+    for x in more:
+        x.close()
     a.close()
 
 
@@ -83,6 +92,12 @@ def test_align_files_reports_errors(data_dir, tmp_path):
     with pytest.raises(capi.ThermiteError) as e:
         capi.align_files(a, [bad], tmp_path / "o.sam", capi.FMT_SAM)
     assert e.value.code == capi.ERR_FORMAT
+    # a read this build cannot take (longer than 65535 bases) fails the run by name: the reference would align it or panic
+    big = tmp_path / "big.fastq"
+    big.write_bytes(b"@ok\nACGTACGTACGT\n+\n!!!!!!!!!!!!\n@giant read\n" + b"ACGT" * 17000 + b"\n+\n" + b"!" * 68000 + b"\n")
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.align_files(a, [big], tmp_path / "o.sam", capi.FMT_SAM)
+    assert e.value.code == capi.ERR_UNSUPPORTED and "giant read" in str(e.value)
     with pytest.raises(capi.ThermiteError) as e:
         capi.align_files(a, [data_dir + "/test_query.fastq"], tmp_path / "o.xyz", 7)
     assert e.value.code == capi.ERR_INVALID_ARG

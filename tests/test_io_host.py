@@ -267,3 +267,88 @@ def test_oracle_writer_reproduces_committed_sam_paf(data_dir, golden_dir):
     nb, sb, qb = [n.encode() for n in names], [bytes(s) for s in seqs], [bytes(q) for q in quals]
     assert ow.sam_header(t) + ow.format_batch(t, nb, sb, qb, res, "sam") == open(golden_dir + "/test_query.sam", "rb").read()
     assert ow.format_batch(t, nb, sb, qb, res, "paf") == open(golden_dir + "/test_query.paf", "rb").read()
+
+
+# ---- the whole-file driver's parallel parsing: the block cutter and the block parser against the sequential parser ----
+@pytest.mark.parametrize("per_block", [1, 2, 7, 1000])
+def test_fastq_block_parser_equals_sequential_parser(data_dir, tmp_path, per_block):
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(533):
+        L = int(rng.integers(0, 160))
+        seq = bytes(np.frombuffer(b"ACGTNacgt", np.uint8)[rng.integers(0, 9, L)])
+        qual = bytes(rng.integers(33, 74, L).astype(np.uint8))  # includes '@' and '+' as quality characters
+        recs.append(b"@r%d some words %d\n" % (i, i * 7) + seq + b"\n+\n" + qual + b"\n")
+    variants = {"plain": b"".join(recs), "no_final_newline": b"".join(recs)[:-1], "crlf": b"".join(recs).replace(b"\n", b"\r\n"),
+                "blank_tail": b"".join(recs) + b"\n\n"}
+    for name, data in variants.items():
+        for gz in (False, True):
+            p = tmp_path / ("%s.fastq%s" % (name, ".gz" if gz else ""))
+            (gzip.open(p, "wb") if gz else open(p, "wb")).write(data)
+            want = _collect(capi.FastqReader(p), 100)
+            b = capi.FastqReader(p).all_by_blocks(per_block)
+            got = _collect_one(b)
+            assert got == want, (name, gz)
+    # malformed records are errors in the block parser too
+    for bad in (b"@r\nACGT\n+\n!!\n", b"@r\nACGT\nACGT\n!!!!\n", b"@r\nACGT\n", b"@a\nAC\n+\n!!\n\n@b\nAC\n+\n!!\n"):
+        q = tmp_path / "bad.fastq"
+        q.write_bytes(bad)
+        with pytest.raises(capi.ThermiteError) as e:
+            capi.FastqReader(q).all_by_blocks(per_block)
+        assert e.value.code == capi.ERR_FORMAT
+
+
+def _collect_one(b):
+    names, seqs, quals = [], [], []
+    for i in range(len(b["offsets"]) - 1):
+        s, e = int(b["offsets"][i]), int(b["offsets"][i + 1])
+        seqs.append(bytes(b["bases"][s:e]))
+        quals.append(bytes(b["quals"][s:e]))
+        names.append(bytes(b["names"][int(b["name_off"][i]): int(b["name_off"][i + 1])]))
+    return names, seqs, quals
+
+
+def test_fastq_read_errors_are_not_end_of_file(data_dir, tmp_path):
+    """a truncated or corrupt gzip stream is THM_ERR_IO, never a silently shorter input (needletail returns the error,
+    reference src/aligner.rs:52-55)"""
+    raw = open(data_dir + "/test_query.fastq", "rb").read() * 400
+    good = tmp_path / "g.fastq.gz"
+    with gzip.open(good, "wb") as f:
+        f.write(raw)
+    z = open(good, "rb").read()
+    cut = tmp_path / "cut.fastq.gz"
+    cut.write_bytes(z[: len(z) // 2])
+    corrupt = tmp_path / "bad.fastq.gz"
+    zb = bytearray(z)
+    for k in range(len(zb) // 3, len(zb) // 3 + 64):
+        zb[k] ^= 0x5A
+    corrupt.write_bytes(bytes(zb))
+    n_good = sum(len(x) for x in [_collect(capi.FastqReader(good), 1000)[0]])
+    assert n_good == 4000
+    for p in (cut, corrupt):
+        for how in ("seq", "blocks"):
+            with pytest.raises(capi.ThermiteError) as e:
+                if how == "seq":
+                    _collect(capi.FastqReader(p), 1000)
+                else:
+                    capi.FastqReader(p).all_by_blocks(500)
+            assert e.value.code == capi.ERR_IO, (p, how)
+
+
+def test_index_load_rejects_absurd_header_counts(data_dir, tmp_path):
+    """header counts larger than the file (whose products would wrap around) are a format error, not an allocation"""
+    import struct
+    t = refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    ix = capi.Index(t)
+    p = tmp_path / "i.thmidx"
+    ix.save(p)
+    raw = bytearray(open(p, "rb").read())
+    for field in range(1, 9):  # n_text .. names_bytes
+        for val in (2**63, 2**61 + 12345, 2**40):
+            bad = bytearray(raw)
+            bad[8 * field: 8 * field + 8] = struct.pack("<Q", val)
+            q = tmp_path / "bad.thmidx"
+            q.write_bytes(bytes(bad))
+            with pytest.raises(capi.ThermiteError) as e:
+                capi.Index.load(q)
+            assert e.value.code == capi.ERR_FORMAT

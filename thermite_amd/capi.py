@@ -110,7 +110,7 @@ IO_ABI_SYMBOLS = [
     "thm_index_create_from_files", "thm_index_set_names", "thm_index_save", "thm_index_load", "thm_index_tables",
     "thm_index_contig_name", "thm_index_tx_id", "thm_index_gene_id", "thm_index_gene_name", "thm_fastq_open",
     "thm_fastq_next_batch", "thm_fastq_close", "thm_writer_create", "thm_writer_free", "thm_writer_header",
-    "thm_writer_format_batch", "thm_writer_trailer", "thm_align_files",
+    "thm_writer_format_batch", "thm_writer_trailer", "thm_align_files", "thm_align_files_multi",
 ]
 ERR_IO, ERR_FORMAT = -8, -9
 FMT_PAF, FMT_SAM, FMT_BAM = 0, 1, 2
@@ -208,6 +208,9 @@ def lib():
     L.thm_fastq_next_batch.restype = i32
     L.thm_fastq_next_batch.argtypes = [vp, u64, vp]
     L.thm_fastq_close.argtypes = [vp]
+    if hasattr(L, "thm_debug_fastq_blocks"):
+        L.thm_debug_fastq_blocks.restype = i32
+        L.thm_debug_fastq_blocks.argtypes = [vp, u64, vp]
     L.thm_writer_create.restype = i32
     L.thm_writer_create.argtypes = [vp, i32, u32, vp]
     L.thm_writer_free.argtypes = [vp]
@@ -219,6 +222,8 @@ def lib():
     L.thm_writer_format_batch.argtypes = [vp, vp, vp, vp]
     L.thm_align_files.restype = i32
     L.thm_align_files.argtypes = [vp, vp, u32, cp, i32, u64, u32, vp]
+    L.thm_align_files_multi.restype = i32
+    L.thm_align_files_multi.argtypes = [vp, u32, vp, u32, cp, i32, u64, u32, vp]
     if hasattr(L, "thm_debug_prof_get"):
         L.thm_debug_prof_get.restype = i32
         L.thm_debug_prof_get.argtypes = [vp, vp, i32]
@@ -586,6 +591,17 @@ class FastqReader:
             raise ThermiteError(rc, _last_error())
         self.h = h
 
+    def all_by_blocks(self, reads_per_block):
+        """test hook: the whole file through the parallel driver's block cutter + block parser"""
+        v = ReadBatch()
+        rc = lib().thm_debug_fastq_blocks(self.h, reads_per_block, C.byref(v))
+        if rc != 0:
+            raise ThermiteError(rc, _last_error())
+        off = _copy(v.offsets, v.n_reads + 1, "<u8")
+        noff = _copy(v.name_off, v.n_reads + 1, "<u8")
+        return dict(bases=_copy(v.bases, v.n_bases, np.uint8), offsets=off, quals=_copy(v.quals, v.n_bases, np.uint8),
+                    names=_copy(v.names, int(noff[-1]), np.uint8), name_off=noff)
+
     def next_batch(self, max_reads):
         """-> dict(bases, offsets, quals (None for FASTA), names, name_off) or None at end of file"""
         v = ReadBatch()
@@ -665,11 +681,14 @@ class Writer:
 
 
 def align_files(aligner, fastq_paths, output_path, fmt=FMT_SAM, batch_reads=0, n_threads=0):
-    """align_reads_from_file (src/aligner.rs:22-120): FASTQ files -> one SAM / PAF file; returns the run stats."""
+    """align_reads_from_file (src/aligner.rs:22-120): FASTQ files -> one SAM / PAF / BAM file; returns the run stats.
+    `aligner`: one Aligner, or a list of them (one per GPU, all over the same Index)."""
     paths = _cstr_array([str(p) for p in fastq_paths])
     st = RunStats()
-    rc = lib().thm_align_files(aligner.h, paths, len(fastq_paths), str(output_path).encode(), fmt, batch_reads, n_threads,
-                               C.byref(st))
+    als = list(aligner) if isinstance(aligner, (list, tuple)) else [aligner]
+    arr = (C.c_void_p * len(als))(*[a.h for a in als])
+    rc = lib().thm_align_files_multi(arr, len(als), paths, len(fastq_paths), str(output_path).encode(), fmt, batch_reads, n_threads,
+                                     C.byref(st))
     if rc != 0:
         raise ThermiteError(rc, _last_error())
     return {k: getattr(st, k) for k, _ in RunStats._fields_}

@@ -1,20 +1,26 @@
 // io_driver.cpp -- whole-file driver (include/thermite_io.h): the loop of
-// align_reads_from_file, reference src/aligner.rs:22-120, as three overlapped
-// stages over batches of reads:
-//     parse (FASTQ -> HostBatch)  |  GPU (upload, run, sync, fetch)  |  format + write
-// connected by bounded queues of a few reusable slots, so that the host work
-// either side of the hot path hides behind the GPU (or the other way round:
-// at tens of millions of reads per second on the GPU the host side is the
-// bottleneck).  Records leave in input order.
+// align_reads_from_file, reference src/aligner.rs:22-120, as overlapped stages over
+// batches of reads:
+//     cut     one thread: file bytes (read(2) / zlib) -> blocks of whole FASTQ records
+//     parse   a few threads: block -> batch (names, bases, qualities)
+//     GPU     one thread per aligner (= per GPU): upload, run, sync, fetch
+//     write   one thread: batches in input order -> formatting threads -> pwrite
+// connected by queues over a fixed set of reusable slots, so that the host work either
+// side of the hot path hides behind the GPUs (or the other way round: at tens of millions
+// of reads per second per GPU the host side is the bottleneck).
+// Records leave in input order whatever the number of GPUs.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -29,13 +35,19 @@ using Clock = std::chrono::steady_clock;
 double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
 
 struct Slot {
+  uint64_t seq = 0;  // position of the batch in the input
+  std::vector<char> raw;      // block bytes (gzip input: inflated here) ...
+  const char* raw_ptr = nullptr;  // ... or a range of the memory-mapped input file (plain input: no copy)
+  size_t raw_len = 0;
+  uint64_t first_line = 0;
+  std::string path;
+  bool parsed = false;  // `reads` already holds the batch (sequential parser: FASTA, odd inputs)
   thm::HostBatch reads;
-  thm_batch_view res;  // into the aligner's pinned result buffers (two sets, used alternately)
+  thm_batch_view res;  // into the pinned result buffers of the aligner that ran it (two sets per aligner, used alternately)
   bool aligned = false;
-  bool last = false;  // sentinel: no more batches
 };
 
-// blocking queue of slot pointers
+// blocking queue of slot pointers; nullptr = end of stream
 struct Queue {
   std::mutex mu;
   std::condition_variable cv;
@@ -75,13 +87,25 @@ struct Shared {
 
 }  // namespace
 
-extern "C" int32_t thm_align_files(thm_aligner* a, const char* const* fastq_paths, uint32_t n_paths, const char* output_path,
-                                   int32_t format, uint64_t batch_reads, uint32_t n_threads, thm_run_stats* stats) {
-  if (!a || !fastq_paths || n_paths == 0 || !output_path) return THM_ERR_INVALID_ARG;
+extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t n_aligners, const char* const* fastq_paths,
+                                         uint32_t n_paths, const char* output_path, int32_t format, uint64_t batch_reads,
+                                         uint32_t n_threads, thm_run_stats* stats) {
+  if (!aligners || n_aligners == 0 || !fastq_paths || n_paths == 0 || !output_path) return THM_ERR_INVALID_ARG;
   for (uint32_t i = 0; i < n_paths; i++)
     if (!fastq_paths[i]) return THM_ERR_INVALID_ARG;
+  for (uint32_t i = 0; i < n_aligners; i++)
+    if (!aligners[i]) return THM_ERR_INVALID_ARG;
   if (batch_reads == 0) batch_reads = 250000;
-  const thm_index* ix = thm_aligner_index(a);
+  const thm_index* ix = thm_aligner_index(aligners[0]);
+  for (uint32_t i = 1; i < n_aligners; i++)
+    if (thm_aligner_index(aligners[i]) != ix) {
+      thm::set_global_error("thm_align_files_multi: the aligners must share one index");
+      return THM_ERR_INVALID_ARG;
+    }
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (n_threads == 0) n_threads = std::min(hw, 16u);
+  // parser threads: a block parses at roughly 10 M records/s per thread; the rest of the budget formats
+  const unsigned n_parsers = std::max(1u, std::min(4u, n_threads / 4));
   thm_writer* w = nullptr;
   int rc = thm_writer_create(ix, format, n_threads, &w);
   if (rc != THM_OK) return rc;
@@ -110,20 +134,34 @@ extern "C" int32_t thm_align_files(thm_aligner* a, const char* const* fastq_path
 
   thm_run_stats st;
   memset(&st, 0, sizeof st);
+  std::mutex st_mu;  // parse_s / gpu_s are summed by several threads
   const auto t_start = Clock::now();
   Shared sh;
-  constexpr int N_SLOTS = 4;
-  // the aligner keeps the results of the last two fetches: batch j may be fetched only
-  // once batch j-2 has left the writer
+  // every aligner keeps the results of its last two fetches: two batches per GPU may be between fetch and write,
+  // one more is running; the parsers and the cutter work ahead of that
+  const unsigned n_slots = 3 * n_aligners + n_parsers + 2;
+  std::vector<Slot> slots(n_slots);
+  Queue q_free, q_raw;
+  for (auto& s : slots) q_free.push(&s);
+  // parsed batches are handed to the GPU threads strictly in input order (parsers may finish out of order; an aligner
+  // that ran ahead of a batch it would later have to wait for could block the writer for good)
+  std::mutex par_mu;
+  std::condition_variable par_cv;
+  std::map<uint64_t, Slot*> parsed;
+  uint64_t next_align = 0;
+  bool parse_done = false;
+  // finished batches, by sequence number, for the writer
   std::mutex done_mu;
   std::condition_variable done_cv;
-  uint64_t n_written = 0;
-  Slot slots[N_SLOTS];
-  Queue q_free, q_parsed, q_aligned;
-  for (auto& s : slots) q_free.push(&s);
+  std::map<uint64_t, Slot*> done;
+  uint64_t n_batches_cut = 0;  // set when the cutter has seen the end of the input
+  bool cut_done = false;
+  uint64_t n_written = 0;  // batches the writer has finished (guarded by done_mu)
 
-  // ---- stage 1: parse ----
-  std::thread parser([&] {
+  std::vector<std::pair<const char*, size_t>> maps;
+  // ---- stage 1: cut the input into blocks of whole records ----
+  std::thread cutter([&] {
+    uint64_t seq = 0;
     for (uint32_t pi = 0; pi < n_paths && !sh.failed(); pi++) {
       thm_fastq* r = nullptr;
       int prc = thm_fastq_open(fastq_paths[pi], &r);
@@ -131,126 +169,342 @@ extern "C" int32_t thm_align_files(thm_aligner* a, const char* const* fastq_path
         sh.set(prc, thm_last_error(nullptr));
         break;
       }
+      const bool fast = thm::fastq_is_plain_fastq(r);
+      // a plain (not gzip) FASTQ file is mapped and cut in place: a block is a range of the mapping
+      const char* map = nullptr;
+      size_t map_len = 0, map_pos = 0;
+      uint64_t map_line = 1;
+      if (fast) {
+        unsigned char magic[2] = {0, 0};
+        const int fd = open(fastq_paths[pi], O_RDONLY);
+        struct stat ms;
+        if (fd >= 0 && fstat(fd, &ms) == 0 && S_ISREG(ms.st_mode) && ms.st_size > 0 && pread(fd, magic, 2, 0) == 2 &&
+            !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+          void* m = mmap(nullptr, (size_t)ms.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+          if (m != MAP_FAILED) {
+            map = (const char*)m;
+            map_len = (size_t)ms.st_size;
+            (void)madvise(m, map_len, MADV_SEQUENTIAL);
+          }
+        }
+        if (fd >= 0) close(fd);
+      }
+      auto count_nl = [](const char* p, size_t n) {
+        size_t c = 0;
+        for (size_t i = 0; i < n; i++) c += p[i] == '\n';
+        return c;
+      };
       for (;;) {
         Slot* s = q_free.pop();
-        s->last = false;
+        s->seq = seq;
+        s->parsed = false;
+        s->aligned = false;
+        s->path = fastq_paths[pi];
         const auto t0 = Clock::now();
-        prc = thm::fastq_fill(r, batch_reads, s->reads);
-        st.parse_s += secs(t0, Clock::now());
-        if (prc != THM_OK || sh.failed() || s->reads.n_reads() == 0) {
+        uint64_t n_lines = 0;
+        s->raw_ptr = nullptr;
+        if (map) {
+          // the position behind the (4 x batch_reads)-th newline from map_pos, found a span at a time
+          const uint64_t want = batch_reads * 4;
+          size_t p0 = map_pos, p = map_pos;
+          while (p < map_len && n_lines < want) {
+            const size_t span = std::min<size_t>(map_len - p, 1u << 20);
+            const size_t nl = count_nl(map + p, span);
+            if (n_lines + nl < want) {
+              n_lines += nl;
+              p += span;
+              continue;
+            }
+            const char* q = map + p;
+            while (n_lines < want) {
+              q = (const char*)memchr(q, '\n', (size_t)(map + p + span - q)) + 1;
+              n_lines++;
+            }
+            p = (size_t)(q - map);
+          }
+          if (p == map_len && p > p0 && map[p - 1] != '\n') n_lines++;
+          s->raw_ptr = map + p0;
+          s->raw_len = p - p0;
+          s->first_line = map_line;
+          map_line += n_lines;
+          map_pos = p;
+          prc = THM_OK;
+        } else if (fast) {
+          prc = thm::fastq_next_raw_block(r, batch_reads, s->raw, s->raw_len, n_lines, s->first_line);
+          s->raw_ptr = s->raw.data();
+        } else {  // FASTA and anything that is not plain 4-line FASTQ: the sequential parser
+          prc = thm::fastq_fill(r, batch_reads, s->reads);
+          s->parsed = true;
+          n_lines = s->reads.n_reads();
+        }
+        {
+          std::lock_guard<std::mutex> g(st_mu);
+          st.parse_s += secs(t0, Clock::now());
+        }
+        if (prc != THM_OK || sh.failed() || n_lines == 0) {
           if (prc != THM_OK) sh.set(prc, thm_last_error(nullptr));
           q_free.push(s);
           break;
         }
-        q_parsed.push(s);
+        seq++;
+        q_raw.push(s);
       }
       thm_fastq_close(r);
+      if (map) maps.emplace_back(map, map_len);  // unmapped when every batch has been written
     }
-    Slot* s = q_free.pop();
-    s->last = true;
-    q_parsed.push(s);
+    {
+      std::lock_guard<std::mutex> g(done_mu);
+      n_batches_cut = seq;
+      cut_done = true;
+    }
+    done_cv.notify_all();
+    for (unsigned k = 0; k < n_parsers; k++) q_raw.push(nullptr);
   });
 
-  // ---- stage 3: format + write ----
-  std::thread writer([&] {
+  // ---- stage 2: parse blocks (several threads) ----
+  std::vector<std::thread> parsers;
+  std::mutex parsers_mu;
+  unsigned parsers_left = n_parsers;
+  for (unsigned k = 0; k < n_parsers; k++)
+    parsers.emplace_back([&] {
+      for (;;) {
+        Slot* s = q_raw.pop();
+        if (!s) break;
+        if (!s->parsed && !sh.failed()) {
+          const auto t0 = Clock::now();
+          std::string err;
+          const int prc = thm::fastq_parse_block(s->raw_ptr, s->raw_len, s->path, s->first_line, s->reads, err);
+          {
+            std::lock_guard<std::mutex> g(st_mu);
+            st.parse_s += secs(t0, Clock::now());
+          }
+          if (prc != THM_OK) sh.set(prc, err);
+        }
+        {
+          std::lock_guard<std::mutex> g(par_mu);
+          parsed[s->seq] = s;
+        }
+        par_cv.notify_all();
+      }
+      std::lock_guard<std::mutex> g(parsers_mu);
+      if (--parsers_left == 0) {
+        {
+          std::lock_guard<std::mutex> g2(par_mu);
+          parse_done = true;
+        }
+        par_cv.notify_all();
+      }
+    });
+
+  // ---- stage 3: one thread per aligner ----
+  std::vector<std::thread> gpus;
+  for (uint32_t gi = 0; gi < n_aligners; gi++)
+    gpus.emplace_back([&, gi] {
+      thm_aligner* a = aligners[gi];
+      std::deque<uint64_t> fetched;  // sequence numbers of this aligner's fetched batches, oldest first
+      for (;;) {
+        Slot* s = nullptr;
+        {
+          std::unique_lock<std::mutex> g(par_mu);
+          par_cv.wait(g, [&] { return parsed.count(next_align) || (parse_done && parsed.empty()); });
+          auto it = parsed.find(next_align);
+          if (it == parsed.end()) break;
+          s = it->second;
+          parsed.erase(it);
+          next_align++;
+        }
+        par_cv.notify_all();
+        if (!sh.failed()) {
+          const auto t0 = Clock::now();
+          const thm_read_batch rb = s->reads.view();
+          int grc = thm_batch_upload(a, rb.bases, rb.offsets, rb.n_reads);
+          if (grc == THM_OK) grc = thm_batch_run(a);
+          if (grc == THM_OK) grc = thm_batch_sync(a);
+          const auto t1 = Clock::now();
+          // the fetch below reuses the buffers of this aligner's second-last fetch: that batch must have been written
+          if (grc == THM_OK && fetched.size() >= 2) {
+            const uint64_t must = fetched[fetched.size() - 2];
+            std::unique_lock<std::mutex> g(done_mu);
+            done_cv.wait(g, [&] { return n_written > must || sh.failed(); });
+          }
+          const auto t2 = Clock::now();
+          if (grc == THM_OK) grc = thm_batch_fetch(a, &s->res);
+          if (grc == THM_OK && s->res.n_failed_reads) {
+            // the reference aligns every read or panics; a read this build cannot take fails the run, by name
+            uint64_t bad = 0;
+            while (bad < s->res.n_reads && s->res.read_status[bad] == THM_OK) bad++;
+            const thm_read_batch v = s->reads.view();
+            std::string name((const char*)v.names + v.name_off[bad], (size_t)(v.name_off[bad + 1] - v.name_off[bad]));
+            sh.set(s->res.read_status[bad], "read " + name + (s->res.read_status[bad] == THM_ERR_UNSUPPORTED
+                                                                   ? ": longer than 65535 bases, or its DP trace exceeds the device-memory budget"
+                                                                   : ": hits a condition that panics in the reference (lift_mem_to_tx / lift_tx_to_gx)"));
+            grc = s->res.read_status[bad];
+          }
+          if (grc != THM_OK) {
+            sh.set(grc, thm_last_error(a));
+          } else {
+            s->aligned = true;
+            fetched.push_back(s->seq);
+            if (fetched.size() > 4) fetched.pop_front();
+          }
+          std::lock_guard<std::mutex> g(st_mu);
+          st.gpu_s += secs(t0, t1) + secs(t2, Clock::now());
+          if (grc == THM_OK) {
+            st.n_reads += s->res.n_reads;
+            st.n_batches += 1;
+          }
+        }
+        {
+          std::lock_guard<std::mutex> g(done_mu);
+          done[s->seq] = s;
+        }
+        done_cv.notify_all();
+      }
+    });
+
+  // ---- stage 4: format (this thread, on the formatting threads of the writer) and write (one more thread), in input
+  // order; two writer objects are used alternately, so that batch k + 1 is formatted while batch k is written ----
+  {
+    thm_writer* w2 = nullptr;
+    if (thm_writer_create(ix, format, n_threads, &w2) != THM_OK) w2 = nullptr;
+    thm_writer* ws[2] = {w, w2 ? w2 : w};
+    struct WriteJob {
+      Slot* s = nullptr;
+      uint64_t seq = 0;
+      std::vector<const std::string*> chunks;
+      std::vector<uint64_t> at;
+      bool stop = false;
+    };
+    std::mutex wj_mu;
+    std::condition_variable wj_cv;
+    std::deque<WriteJob*> wj_q;
+    WriteJob jobs[2];
+    bool job_busy[2] = {false, false};
     thm_text t;
-    std::vector<const std::string*> chunks;
     if (thm_writer_header(w, &t) == THM_OK && t.len) {
       if (!write_all((const char*)t.data, t.len, file_off)) sh.set(THM_ERR_IO, "short write");
       file_off += t.len;
       st.n_output_bytes += t.len;
     }
-    for (;;) {
-      Slot* s = q_aligned.pop();
-      if (s->last) {
-        if (!sh.failed() && thm_writer_trailer(w, &t) == THM_OK && t.len) {
-          if (!write_all((const char*)t.data, t.len, file_off)) sh.set(THM_ERR_IO, "short write");
-          file_off += t.len;
-          st.n_output_bytes += t.len;
-        }
-        q_free.push(s);
-        break;
+    auto release = [&](Slot* s, uint64_t seq) {
+      {
+        std::lock_guard<std::mutex> g(done_mu);
+        n_written = seq + 1;
       }
+      done_cv.notify_all();
+      q_free.push(s);
+    };
+    std::thread wthread([&] {
+      for (;;) {
+        WriteJob* j;
+        {
+          std::unique_lock<std::mutex> g(wj_mu);
+          wj_cv.wait(g, [&] { return !wj_q.empty(); });
+          j = wj_q.front();
+          wj_q.pop_front();
+        }
+        if (j->stop) break;
+        const auto t1 = Clock::now();
+        std::vector<char> good(j->chunks.size(), 1);
+        auto put = [&](size_t c) { good[c] = write_all(j->chunks[c]->data(), j->chunks[c]->size(), j->at[c]) ? 1 : 0; };
+        if (positional && j->chunks.size() > 1) {
+          std::vector<std::thread> th;
+          for (size_t c = 1; c < j->chunks.size(); c++) th.emplace_back(put, c);
+          put(0);
+          for (auto& x : th) x.join();
+        } else {
+          for (size_t c = 0; c < j->chunks.size(); c++) put(c);
+        }
+        for (char g : good)
+          if (!g) sh.set(THM_ERR_IO, "short write");
+        st.write_s += secs(t1, Clock::now());
+        release(j->s, j->seq);
+        {
+          std::lock_guard<std::mutex> g(wj_mu);
+          job_busy[j - jobs] = false;
+        }
+        wj_cv.notify_all();
+      }
+    });
+    for (uint64_t next = 0;; next++) {
+      Slot* s = nullptr;
+      {
+        std::unique_lock<std::mutex> g(done_mu);
+        done_cv.wait(g, [&] { return done.count(next) || (cut_done && next >= n_batches_cut); });
+        auto it = done.find(next);
+        if (it == done.end()) break;  // the input is exhausted
+        s = it->second;
+        done.erase(it);
+      }
+      const int k = (int)(next & 1);
+      {  // the writer object (and job) of this parity: its previous batch must have left
+        std::unique_lock<std::mutex> g(wj_mu);
+        wj_cv.wait(g, [&] { return !job_busy[k]; });
+      }
+      bool queued = false;
       if (!sh.failed() && s->aligned) {
         const auto t0 = Clock::now();
         const thm_read_batch rb = s->reads.view();
         const thm_batch_view& v = s->res;
-        const int wrc = thm::writer_format_chunks(w, &rb, &v, chunks);
-        const auto t1 = Clock::now();
-        st.format_s += secs(t0, t1);
+        WriteJob& j = jobs[k];
+        const int wrc = thm::writer_format_chunks(ws[k], &rb, &v, j.chunks);
+        st.format_s += secs(t0, Clock::now());
         if (wrc != THM_OK) {
           sh.set(wrc, thm_last_error(nullptr));
         } else {
-          std::vector<uint64_t> at(chunks.size());
-          for (size_t c = 0; c < chunks.size(); c++) {
-            at[c] = file_off;
-            file_off += chunks[c]->size();
-            st.n_output_bytes += chunks[c]->size();
+          j.at.resize(j.chunks.size());
+          for (size_t c = 0; c < j.chunks.size(); c++) {
+            j.at[c] = file_off;
+            file_off += j.chunks[c]->size();
+            st.n_output_bytes += j.chunks[c]->size();
           }
-          std::vector<char> good(chunks.size(), 1);
-          auto put = [&](size_t c) { good[c] = write_all(chunks[c]->data(), chunks[c]->size(), at[c]) ? 1 : 0; };
-          if (positional && chunks.size() > 1) {
-            std::vector<std::thread> th;
-            for (size_t c = 1; c < chunks.size(); c++) th.emplace_back(put, c);
-            put(0);
-            for (auto& x : th) x.join();
-          } else {
-            for (size_t c = 0; c < chunks.size(); c++) put(c);
-          }
-          for (char g : good)
-            if (!g) sh.set(THM_ERR_IO, "short write");
-          st.write_s += secs(t1, Clock::now());
           for (uint64_t r = 0; r < v.n_reads; r++) {
-            const uint64_t k = v.read_aln_off[r + 1] - v.read_aln_off[r];
-            st.n_aligned_reads += k != 0;
-            st.n_records += k ? k : (format == THM_FMT_PAF ? 0 : 1);
+            const uint64_t kk = v.read_aln_off[r + 1] - v.read_aln_off[r];
+            st.n_aligned_reads += kk != 0;
+            st.n_records += kk ? kk : (format == THM_FMT_PAF ? 0 : 1);
           }
+          j.s = s;
+          j.seq = next;
+          {
+            std::lock_guard<std::mutex> g(wj_mu);
+            job_busy[k] = true;
+            wj_q.push_back(&j);
+          }
+          wj_cv.notify_all();
+          queued = true;
         }
       }
-      {
-        std::lock_guard<std::mutex> g(done_mu);
-        n_written++;
+      if (!queued) {
+        // nothing to write for this batch: it still leaves in order behind the writes that are queued
+        std::unique_lock<std::mutex> g(wj_mu);
+        wj_cv.wait(g, [&] { return !job_busy[0] && !job_busy[1]; });
+        g.unlock();
+        release(s, next);
       }
-      done_cv.notify_all();
-      q_free.push(s);
     }
-  });
-
-  // ---- stage 2: GPU (this thread; the aligner handle is single-threaded) ----
-  uint64_t n_pushed = 0;  // batches handed to the writer so far
-  for (;;) {
-    Slot* s = q_parsed.pop();
-    if (s->last) {
-      q_aligned.push(s);
-      break;
+    {
+      std::unique_lock<std::mutex> g(wj_mu);
+      wj_cv.wait(g, [&] { return !job_busy[0] && !job_busy[1]; });
     }
-    s->aligned = false;
-    if (!sh.failed()) {
-      const auto t0 = Clock::now();
-      const thm_read_batch rb = s->reads.view();
-      int grc = thm_batch_upload(a, rb.bases, rb.offsets, rb.n_reads);
-      if (grc == THM_OK) grc = thm_batch_run(a);
-      auto t1 = Clock::now();
-      if (grc == THM_OK) {
-        std::unique_lock<std::mutex> g(done_mu);
-        done_cv.wait(g, [&] { return n_written + 1 >= n_pushed; });
-      }
-      const auto t2 = Clock::now();
-      if (grc == THM_OK) grc = thm_batch_fetch(a, &s->res);
-      if (grc != THM_OK) {
-        sh.set(grc, thm_last_error(a));
-      } else {
-        s->aligned = true;
-        st.n_reads += s->res.n_reads;
-        st.n_batches += 1;
-      }
-      st.gpu_s += secs(t0, t1) + secs(t2, Clock::now());
+    WriteJob stop;
+    stop.stop = true;
+    {
+      std::lock_guard<std::mutex> g(wj_mu);
+      wj_q.push_back(&stop);
     }
-    n_pushed++;
-    q_aligned.push(s);
+    wj_cv.notify_all();
+    wthread.join();
+    if (!sh.failed() && thm_writer_trailer(w, &t) == THM_OK && t.len) {
+      if (!write_all((const char*)t.data, t.len, file_off)) sh.set(THM_ERR_IO, "short write");
+      file_off += t.len;
+      st.n_output_bytes += t.len;
+    }
+    if (w2) thm_writer_free(w2);
   }
-  parser.join();
-  writer.join();
+  cutter.join();
+  for (auto& m : maps) munmap((void*)m.first, m.second);
+  for (auto& x : parsers) x.join();
+  for (auto& x : gpus) x.join();
   bool ok = true;
   if (!to_stdout) ok = close(fo) == 0;
   if (!ok) sh.set(THM_ERR_IO, std::string("error closing ") + output_path);
@@ -259,4 +513,11 @@ extern "C" int32_t thm_align_files(thm_aligner* a, const char* const* fastq_path
   if (stats) *stats = st;
   if (sh.rc != THM_OK) thm::set_global_error(sh.msg);
   return sh.rc;
+}
+
+extern "C" int32_t thm_align_files(thm_aligner* a, const char* const* fastq_paths, uint32_t n_paths, const char* output_path,
+                                   int32_t format, uint64_t batch_reads, uint32_t n_threads, thm_run_stats* stats) {
+  if (!a) return THM_ERR_INVALID_ARG;
+  thm_aligner* one[1] = {a};
+  return thm_align_files_multi(one, 1, fastq_paths, n_paths, output_path, format, batch_reads, n_threads, stats);
 }

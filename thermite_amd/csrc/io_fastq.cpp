@@ -170,6 +170,169 @@ static int fastq_fill_raw(thm_fastq* r, uint64_t max_reads, HostBatch& b, size_t
   return THM_OK;
 }
 
+// ---- block cutting and block parsing for the parallel driver ----
+const std::string& fastq_path(const thm_fastq* r) { return r->path; }
+
+static bool refill(thm_fastq* r) {  // more bytes behind [pos, end); false at the end of the input
+  if (r->eof) return false;
+  const char* p;
+  size_t len;
+  // next_line's refill logic, without consuming a line: ask for a line only when none is buffered
+  const size_t before = r->end - r->pos;
+  // keep the unread tail, read behind it
+  if (r->pos > 0) {
+    memmove(r->buf.data(), r->buf.data() + r->pos, r->end - r->pos);
+    r->end -= r->pos;
+    r->pos = 0;
+  }
+  if (r->end == r->buf.size()) r->buf.resize(r->buf.size() * 2);
+  const size_t room = std::min<size_t>(r->buf.size() - r->end, 1u << 30);
+  const long n = r->f ? (long)gzread(r->f, r->buf.data() + r->end, (unsigned)room) : (long)read(r->fd, r->buf.data() + r->end, room);
+  if (n > 0) r->end += (size_t)n;
+  if (r->f) {
+    if (n < (long)room) {
+      int zerr = Z_OK;
+      const char* zmsg = gzerror(r->f, &zerr);
+      if (n < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) {
+        r->io_err = true;
+        r->io_msg = "gzip read error in " + r->path + ": " + (zmsg && *zmsg ? zmsg : "corrupt or truncated stream");
+        r->eof = true;
+      } else if (n == 0) {
+        r->eof = true;
+      }
+    }
+  } else if (n < 0) {
+    if (errno != EINTR) {
+      r->io_err = true;
+      r->io_msg = "read error in " + r->path + ": " + strerror(errno);
+      r->eof = true;
+    }
+  } else if (n == 0) {
+    r->eof = true;
+  }
+  (void)p;
+  (void)len;
+  return (r->end - r->pos) > before;
+}
+
+bool fastq_is_plain_fastq(thm_fastq* r) {
+  while (r->pos == r->end && refill(r)) {
+  }
+  return r->pos < r->end && r->buf[r->pos] == '@' && !r->have_pending;
+}
+
+static inline size_t count_newlines(const char* p, size_t n) {
+  size_t c = 0;
+  for (size_t i = 0; i < n; i++) c += p[i] == '\n';  // vectorised by the compiler
+  return c;
+}
+
+int fastq_next_raw_block(thm_fastq* r, uint64_t max_reads, std::vector<char>& raw, size_t& raw_len, uint64_t& n_lines,
+                         uint64_t& first_line) {
+  const uint64_t want = max_reads * 4;
+  raw_len = 0;
+  n_lines = 0;
+  first_line = r->lineno + 1;
+  for (;;) {
+    if (r->pos == r->end && !refill(r)) break;
+    const char* p = r->buf.data() + r->pos;
+    size_t avail = r->end - r->pos;
+    size_t take = avail;
+    const size_t nl = count_newlines(p, avail);
+    uint64_t got = nl;
+    if (n_lines + nl >= want) {  // the block ends inside this span: find its last newline
+      uint64_t need = want - n_lines;
+      const char* q = p;
+      while (need) {
+        q = (const char*)memchr(q, '\n', (size_t)(p + avail - q)) + 1;
+        need--;
+      }
+      take = (size_t)(q - p);
+      got = want - n_lines;
+    }
+    if (raw_len + take > raw.size()) raw.resize(std::max(raw.size() * 2, raw_len + take + 4096));
+    memcpy(raw.data() + raw_len, p, take);
+    raw_len += take;
+    r->pos += take;
+    n_lines += got;
+    if (n_lines >= want) break;
+  }
+  if (raw_len && raw[raw_len - 1] != '\n') n_lines++;  // a last line without its newline
+  r->lineno += n_lines;
+  if (r->io_err) return fail(THM_ERR_IO, r->io_msg);
+  return THM_OK;
+}
+
+int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t first_line, HostBatch& b, std::string& err) {
+  b.clear();
+  const char* end = p + n;
+  uint64_t line = first_line;
+  auto next = [&](const char*& s, size_t& len) -> bool {
+    if (p >= end) return false;
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    s = p;
+    len = nl ? (size_t)(nl - p) : (size_t)(end - p);
+    p = nl ? nl + 1 : end;
+    line++;
+    while (len && s[len - 1] == '\r') len--;
+    return true;
+  };
+  // sizes are known up to a constant: one pass of appends into storage reserved once
+  if (b.bases.size() < n / 2 + 4096) b.bases.resize(n / 2 + 4096);
+  if (b.quals.size() < n / 2 + 4096) b.quals.resize(n / 2 + 4096);
+  if (b.names.size() < n + 4096) b.names.resize(n + 4096);
+  size_t nb = 0, nq = 0, nn = 0;
+  const char* s;
+  size_t len;
+  while (next(s, len)) {
+    const uint64_t at = line - 1;
+    auto where = [&] { return path + ":" + std::to_string(at); };
+    if (len == 0) {  // empty lines are tolerated at the very end only
+      const char* t = p;
+      while (t < end && (*t == '\n' || *t == '\r')) t++;
+      if (t == end) break;
+      err = "expected '@' at " + where();
+      return THM_ERR_FORMAT;
+    }
+    if (s[0] != '@') {
+      err = "expected '@' at " + where();
+      return THM_ERR_FORMAT;
+    }
+    memcpy(b.names.data() + nn, s + 1, len - 1);
+    nn += len - 1;
+    b.name_off.push_back(nn);
+    if (!next(s, len)) {
+      err = "truncated FASTQ record at " + where();
+      return THM_ERR_FORMAT;
+    }
+    memcpy(b.bases.data() + nb, s, len);
+    const size_t slen = len;
+    if (!next(s, len) || len == 0 || s[0] != '+') {
+      err = "FASTQ record without a '+' line at " + where();
+      return THM_ERR_FORMAT;
+    }
+    if (!next(s, len)) {
+      if (slen != 0) {
+        err = "truncated FASTQ record at " + where();
+        return THM_ERR_FORMAT;
+      }
+      len = 0;
+    }
+    if (len != slen) {
+      err = "FASTQ quality length differs from sequence length at " + where();
+      return THM_ERR_FORMAT;
+    }
+    memcpy(b.quals.data() + nq, s, len);
+    nb += slen;
+    nq += len;
+    b.offsets.push_back(nb);
+  }
+  b.nb = nb;
+  b.nq = nq;
+  b.nn = nn;
+  return THM_OK;
+}
+
 }  // namespace thm
 
 extern "C" {
@@ -205,6 +368,38 @@ void thm_fastq_close(thm_fastq* r) {
   if (r->f) gzclose(r->f);
   if (r->fd >= 0) close(r->fd);
   delete r;
+}
+
+// test hook: the parallel driver's block cutter + block parser over a whole file; the batches are concatenated into the
+// reader's own storage so that the result can be compared with the sequential parser's (thm_fastq_next_batch)
+int32_t thm_debug_fastq_blocks(thm_fastq* r, uint64_t max_reads_per_block, thm_read_batch* out) {
+  if (!r || !out) return THM_ERR_INVALID_ARG;
+  thm::HostBatch& all = r->own;
+  all.clear();
+  if (!thm::fastq_is_plain_fastq(r)) return fail(THM_ERR_FORMAT, "not a plain FASTQ input");
+  std::vector<char> raw;
+  thm::HostBatch b;
+  for (;;) {
+    size_t raw_len = 0;
+    uint64_t n_lines = 0, first_line = 0;
+    int rc = thm::fastq_next_raw_block(r, max_reads_per_block, raw, raw_len, n_lines, first_line);
+    if (rc != THM_OK) return rc;
+    if (n_lines == 0) break;
+    std::string err;
+    rc = thm::fastq_parse_block(raw.data(), raw_len, r->path, first_line, b, err);
+    if (rc != THM_OK) return fail(rc, err);
+    const thm_read_batch v = b.view();
+    for (uint64_t i = 0; i < v.n_reads; i++) {
+      const size_t L = (size_t)(v.offsets[i + 1] - v.offsets[i]), N = (size_t)(v.name_off[i + 1] - v.name_off[i]);
+      thm::put(all.bases, all.nb, (const char*)v.bases + v.offsets[i], L);
+      thm::put(all.quals, all.nq, (const char*)v.quals + v.offsets[i], L);
+      thm::put(all.names, all.nn, (const char*)v.names + v.name_off[i], N);
+      all.offsets.push_back(all.nb);
+      all.name_off.push_back(all.nn);
+    }
+  }
+  *out = all.view();
+  return THM_OK;
 }
 
 int32_t thm_fastq_next_batch(thm_fastq* r, uint64_t max_reads, thm_read_batch* out) {

@@ -38,6 +38,18 @@ struct HostBatch {
 // up to max_reads further records of the reader into `b` (cleared first)
 int fastq_fill(thm_fastq* r, uint64_t max_reads, HostBatch& b);
 
+// Parallel parsing (the whole-file driver): the reader thread only cuts the byte stream into blocks of whole
+// 4-line FASTQ records, parser threads turn blocks into batches.
+//   fastq_is_plain_fastq   the input starts with '@' (FASTA and anything else take the sequential parser)
+//   fastq_next_raw_block   up to max_reads records as raw bytes (`raw` reused; n_lines = 4 x records, except for a
+//                          truncated last record, which the block parser reports); 0 lines at the end of the input
+//   fastq_parse_block      strict 4-line records (CR LF tolerated, empty lines only at the very end of the input)
+bool fastq_is_plain_fastq(thm_fastq* r);
+int fastq_next_raw_block(thm_fastq* r, uint64_t max_reads, std::vector<char>& raw, size_t& raw_len, uint64_t& n_lines,
+                         uint64_t& first_line);
+int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t first_line, HostBatch& b, std::string& err);
+const std::string& fastq_path(const thm_fastq* r);
+
 // thm_writer_format_batch without the final concatenation: the text of the batch is
 // chunks[0] ++ chunks[1] ++ ... (one chunk per formatting thread, valid until the next call on `w`)
 int writer_format_chunks(thm_writer* w, const thm_read_batch* reads, const thm_batch_view* res,

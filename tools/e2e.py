@@ -33,7 +33,7 @@ a = capi.Aligner(ix, capi.CI_OPTS)
 for fmt, name in ((capi.FMT_SAM, "sam"), (capi.FMT_PAF, "paf")):
     for rep in range(2):
         out = "/tmp/thm_e2e_out.%s" % name
-        st = capi.align_files(a, [path], out, fmt, batch_reads=500000, n_threads=threads)
+        st = capi.align_files(a, [path], out, fmt, batch_reads=250000, n_threads=threads)
         print("%s run %d: %.2f Mreads/s wall %.2fs | parse %.2fs gpu %.2fs format %.2fs write %.2fs | %d batches, %.0f MB out" % (
             name, rep, st["n_reads"] / st["wall_s"] / 1e6, st["wall_s"], st["parse_s"], st["gpu_s"], st["format_s"], st["write_s"],
             st["n_batches"], st["n_output_bytes"] / 1e6), flush=True)
