@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--total-reads", type=int, default=None, help="strong scaling: one stream of this many reads sharded over the ranks "
                                                                     "(default at N > 1: 50 000 000, BASELINE configs[3])")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the timed steps rotate over (weak mode)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight: 2 launches step i + 1 (another aligner, another HIP stream) before step i is waited for, "
+                         "so that the seed kernels of one batch fill the tail of the extend kernel of the other")
     ap.add_argument("--read-len", type=int, default=91)
     ap.add_argument("--ref-len", type=int, default=int(os.environ.get("THM_BENCH_REF_LEN", "0")) or None)
     ap.add_argument("--opts", choices=["ci", "default"], default="ci")
@@ -197,12 +200,16 @@ def main():
     stage_ms = {k: 0.0 for k in capi.TIMING_NAMES}
     barrier()
     t0 = time.perf_counter()
-    for i in range(K):
-        a = aligners[i % NB]
-        a.run()
-        a.sync()  # stream sync + pool-overflow check; HIP-event stage times of this launch
-        for k, v in a.timings().items():
-            stage_ms[k] += v
+    depth = max(1, min(args.inflight, NB))
+    for i in range(K + depth - 1):
+        if i < K:
+            aligners[i % NB].run()
+        j = i - (depth - 1)
+        if j >= 0:
+            a = aligners[j % NB]
+            a.sync()  # stream sync + pool-overflow check; HIP-event stage times of this launch
+            for k, v in a.timings().items():
+                stage_ms[k] += v
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -335,7 +342,7 @@ def main():
                     "-k20 -s0 --intron-mode" if args.opts == "ci" else "defaults (-k20 -s0.66)",
                     "" if args.percent is None else " with -s%g" % args.percent),
                 "reads_per_gpu_per_step": reads_this_rank, "read_len": L, "ref_len": ref_len, "opts": args.opts,
-                "coord_bytes": index.coord_bytes,
+                "coord_bytes": index.coord_bytes, "batches_in_flight": max(1, min(args.inflight, NB)),
                 "parallelism": "reads sharded over %d GPU(s), index replicated, 1 counter all-reduce" % world,
             },
             "roofline": roofline,

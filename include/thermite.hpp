@@ -201,8 +201,9 @@ inline thm_run_stats align_reads_from_file(Aligner& aligner, const std::vector<s
 }
 
 // wrapper::ThermiteAligner, src/wrapper.rs:20-123: index file in, one read per call, SAM records out.
-// align_read returns the records as SAM text lines (the reference converts the same text to
-// rust_htslib Records and strips the TX/GX/GN/RE tags there, src/wrapper.rs:126-141).
+// align_read returns the records as SAM text lines without the TX / GX / GN / RE tags: the reference converts the same
+// text to rust_htslib Records and removes those four tags (src/wrapper.rs:126-141, cellranger adds its own);
+// align_read_with_tags keeps them (the lines `thermite align` writes, src/aln_writer.rs:170-219).
 class ThermiteAligner {
  public:
   explicit ThermiteAligner(const std::string& index_path, int device = 0)
@@ -216,6 +217,29 @@ class ThermiteAligner {
     header_.assign((const char*)t.data, t.len);
   }
   std::vector<std::string> align_read(const std::string& name, const std::string& read, const std::string& qual) {
+    std::vector<std::string> out = align_read_with_tags(name, read, qual);
+    for (std::string& rec : out) {  // record.remove_aux(b"TX" | b"GX" | b"GN" | b"RE"), src/wrapper.rs:136-139
+      std::string kept;
+      std::size_t pos = 0;
+      int field = 0;
+      while (pos <= rec.size()) {
+        std::size_t tab = rec.find('\t', pos);
+        if (tab == std::string::npos) tab = rec.size();
+        const bool drop = field >= 11 && tab - pos >= 3 && rec[pos + 2] == ':' &&
+                          ((rec[pos] == 'T' && rec[pos + 1] == 'X') || (rec[pos] == 'G' && rec[pos + 1] == 'X') ||
+                           (rec[pos] == 'G' && rec[pos + 1] == 'N') || (rec[pos] == 'R' && rec[pos + 1] == 'E'));
+        if (!drop) {
+          if (field) kept.push_back('\t');
+          kept.append(rec, pos, tab - pos);
+        }
+        field++;
+        pos = tab + 1;
+      }
+      rec.swap(kept);
+    }
+    return out;
+  }
+  std::vector<std::string> align_read_with_tags(const std::string& name, const std::string& read, const std::string& qual) {
     aligner_.set_opts(opts_);
     const std::uint64_t off[2] = {0, read.size()}, noff[2] = {0, name.size()};
     thm_batch_view v;

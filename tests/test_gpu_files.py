@@ -122,3 +122,6 @@ def test_cpp_thermite_aligner_wrapper(data_dir, golden_dir, tmp_path):
     out = subprocess.run([str(exe), str(idx), "3", "0", data_dir + "/test_query.fastq"], check=True, capture_output=True)
     assert out.stdout == open(os.path.join(golden_dir, "test_query.sam"), "rb").read()
     assert ("est_mem %d" % os.path.getsize(idx)).encode() in out.stderr
+    # align_read proper returns the same records without TX / GX / GN / RE (src/wrapper.rs:136-139)
+    n_rec = len([ln for ln in out.stdout.split(b"\n") if ln and not ln.startswith(b"@")])
+    assert ("stripped_records %d still_tagged 0" % n_rec).encode() in out.stderr

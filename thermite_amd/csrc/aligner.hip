@@ -173,6 +173,10 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
     return bail(fail(nullptr, THM_ERR_HIP, "hipStreamCreate failed"));
   for (auto& e : a->ev)
     if (hipEventCreate(&e) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipEventCreate failed"));
+  if (hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming) != hipSuccess)
+    return bail(fail(nullptr, THM_ERR_HIP, "second stream / events: creation failed"));
   if (a->d_counters.ensure(THM_N_COUNTERS * 8 * 3) != hipSuccess || a->d_queue.ensure(thm::QUEUE_BYTES) != hipSuccess ||
       a->d_fault.ensure(64) != hipSuccess || a->d_cursors.ensure(64) != hipSuccess)
     return bail(fail(nullptr, THM_ERR_OOM, "scratch allocation failed"));
@@ -189,6 +193,7 @@ void thm_aligner_free(thm_aligner* a) {
   if (!a) return;
   (void)hipSetDevice(a->device);
   if (a->stream) (void)hipStreamSynchronize(a->stream);
+  if (a->stream2) (void)hipStreamSynchronize(a->stream2);
   DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->d_cursors, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4,
                  &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->s_smems, &a->s_off, &a->s_cnt,
                  &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops, &a->e_nalns,
@@ -202,6 +207,9 @@ void thm_aligner_free(thm_aligner* a) {
   }
   for (auto& e : a->ev)
     if (e) (void)hipEventDestroy(e);
+  if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
+  if (a->ev_join) (void)hipEventDestroy(a->ev_join);
+  if (a->stream2) (void)hipStreamDestroy(a->stream2);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   delete a;
 }

@@ -87,6 +87,8 @@ struct thm_aligner {
   int device = 0;
   int n_cu = 256;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // the team kernel runs beside the wave-per-read kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   thm_align_opts opts;
   std::string err;
 

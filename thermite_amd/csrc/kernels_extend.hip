@@ -570,7 +570,8 @@ __device__ unsigned long long emit_alignment(W& c, const PP& p, const uint8_t* p
   return off;
 }
 
-constexpr int TEAM_MAX_CHUNKS = 4096;  // chunks of <= 64 hits a team keeps book of (reads beyond that stay with the sequential path)
+constexpr int TEAM_MAX_CHUNKS = 16384;  // chunks a team keeps book of (reads beyond that stay with the sequential path)
+constexpr int TEAM_CHUNK = 4;           // hits per chunk of a team
 
 // per-wave buffer sizes, shared by the kernel's carve-up and the host's sizing functions
 struct ExtCaps {
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
   __shared__ int t_res[TW][8];        // per wave and round: accepted candidates, state changed?, band, X-drop, best score, per-read fault bits
   __shared__ int t_state[4];          // the state in force at chunk t_ctl[1]: band, X-drop, best score
   __shared__ unsigned t_ctl[4];       // [0] list slot of the read, [1] first chunk of the round, [2] accepted so far, [3] per-read fault bits
-  __shared__ unsigned short t_nacc[TM ? TEAM_MAX_CHUNKS : 1];  // accepted candidates per finished chunk
+  __shared__ unsigned char t_nacc[TM ? TEAM_MAX_CHUNKS : 1];  // accepted candidates per finished chunk (<= TEAM_CHUNK)
   typedef WctxT<GS> Wctx;
   // The parameter block (about 80 dwords) is read from the kernel-argument segment where it is
   // needed (scalar loads, THM_KARG_QUAL = volatile keeps them at their use sites) instead of being
@@ -830,6 +831,10 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
     // ---- team bookkeeping (TEAM > 0; see the comment at the kernel's head) ----
     unsigned t_base = 0, t_total = 0;
     if constexpr (TM) {
+      for (uint32_t si = 0; si < n_sm; si++) {  // chunks of the read: every SMEM's occurrences in chunks of TEAM_CHUNK
+        const uint64_t cnt = (si == 0) ? (uint64_t)(rec.hi0 - rec.lo0) : (uint64_t)(uload(&p.smems[s0 + si].hi) - uload(&p.smems[s0 + si].lo));
+        t_total += (unsigned)((cnt + TEAM_CHUNK - 1) / TEAM_CHUNK);
+      }
       if (threadIdx.x == 0) {
         t_state[0] = band_width;
         t_state[1] = x_drop;
@@ -871,14 +876,24 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
       }
       const int q = sm.qpos, len = sm.len;
       C rr = sm.hi;
-      while (rr > sm.lo) {
-        const uint32_t chunk = (uint32_t)min((C)64, (C)(rr - sm.lo));
-        if (TM && cc != my_chunk) {  // somebody else's chunk (or one that is finished)
-          rr -= chunk;
-          h_start += chunk;
-          cc++;
+      if constexpr (TM) {
+        // a team works in chunks of TEAM_CHUNK hits (the finer the chunks, the less is redone when a hit moves the
+        // state); a wave goes straight to its own chunk of the round
+        const uint64_t cnt = (uint64_t)(sm.hi - sm.lo);
+        const unsigned n_ch = (unsigned)((cnt + TEAM_CHUNK - 1) / TEAM_CHUNK);
+        if (my_chunk < cc || my_chunk >= cc + n_ch) {
+          cc += n_ch;
+          h_start += cnt;
           continue;
         }
+        const unsigned k = my_chunk - cc;
+        rr = sm.hi - (C)k * (C)TEAM_CHUNK;
+        h_start += (uint64_t)k * TEAM_CHUNK;
+        cc = my_chunk;
+      }
+      while (rr > sm.lo) {
+        const uint32_t chunk = (uint32_t)min((C)(TM ? TEAM_CHUNK : 64), (C)(rr - sm.lo));
+        if (TM && cc != my_chunk) break;  // the wave's one chunk of this round is done
         Cand* const cslot = TM ? cands + h_start : cands;  // a team's chunk writes its candidates from its first hit's slot
         const uint64_t slot_cap = TM ? (uint64_t)chunk : n_hits_cap;
         C my_sa = 0;
@@ -923,6 +938,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
             int t_q, t_len;
             uint8_t* buf;
             uint32_t tx_idx = 0, cur_ent = 0;
+            bool by_coords = false;
             if (!genome_done) {
               // genome window (:212-215)
               const S rs = (S)ref.start;
@@ -996,10 +1012,19 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
               t_q = q + start_offset;
               t_len = t_end - tr_;
               const int tlen = (int)tx.seq_len;
+              // The seed lies inside this exon, and so does every base the genome extensions looked at (R.jmax /
+              // Lt.jmax columns beyond the seed, results that do not depend on anything further: `broke`): the
+              // transcript reads the same bases there (its sequence is assembled from the exons), extend_seed_match
+              // finds the same mismatch next to the seed, and the two SwgExtend::extend calls return what they
+              // returned for the genome window.  Known from the coordinates alone: no transcript window is staged.
+              by_coords = ge.prev_end <= qs && t_q == q && t_len == len && gmemo.R.broke && gmemo.Lt.broke &&
+                          hr + (S)(len + gmemo.R.jmax) <= xe && hr - (S)gmemo.Lt.jmax >= xs;
+              int w0 = 0;
+              if (!by_coords) {
               // window of the transcript around the lifted seed
               const int ws = (tr_ > L + bw) ? tr_ - (L + bw) : 0;
               const int we = min(tlen, tr_ + t_len + L + bw + 1);
-              const int w0 = stage_window(c, c.win, ix.tx_seq + tx.seq_off, ws, we);
+              w0 = stage_window(c, c.win, ix.tx_seq + tx.seq_off, ws, we);
               // extend_seed_match (src/aligner.rs:410-426): ballots of the first mismatch
               {
                 int ext = 0;
@@ -1035,6 +1060,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
                 t_q -= ext;
                 t_len += ext;
               }
+              }
               win0 = (S)w0;
               t_r = (S)tr_;
               lo_abs = 0;
@@ -1044,7 +1070,20 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
             }
             PathT<S> pth;
             bool reused = false;
-            if (genome_done && t_q == q && t_len == len) {
+            if (genome_done && by_coords) {
+              reused = true;
+              pth.score = gx.score;
+              pth.nops = gx.nops;
+              pth.xstart = gx.xstart;
+              pth.xend = gx.xend;
+              pth.ystart = t_r - gmemo.Lt.yend;
+              pth.yend = t_r + t_len + gmemo.R.yend;
+#pragma unroll 1
+              for (int t2 = lane; t2 < gx.nops; t2 += 64) buf[t2] = c.pa[t2];
+              wsync(c);
+              c.calls += 2;  // two extend() calls in the reference's terms
+              PROF_MARK(c, PS_TXPREP);
+            } else if (genome_done && t_q == q && t_len == len) {
               // Same seed on the read: if the transcript window agrees with the genome
               // window on every column the genome extensions looked at (the hit sits
               // inside one exon and the alignment does not reach its ends), the two
@@ -1263,7 +1302,6 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
       break;
     } else {
       // ---- end of a round: which chunks are valid? ----
-      t_total = cc;
       if (t_total > (unsigned)TEAM_MAX_CHUNKS) c.fault |= FAULT_INTERNAL;  // plan_kernel keeps such reads away from the team
       const bool active = my_chunk < t_total;
       const bool changed = active && (band_width != st_bw || x_drop != st_xd || max_aln_score != st_max);
@@ -1294,7 +1332,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
       if (threadIdx.x == 0) {
         unsigned acc = 0, fl = 0;
         for (int w2 = 0; w2 < valid; w2++) {
-          if (t_base + (unsigned)w2 < (unsigned)TEAM_MAX_CHUNKS) t_nacc[t_base + w2] = (unsigned short)t_res[w2][0];
+          if (t_base + (unsigned)w2 < (unsigned)TEAM_MAX_CHUNKS) t_nacc[t_base + w2] = (unsigned char)t_res[w2][0];
           acc += (unsigned)t_res[w2][0];
           fl |= (unsigned)t_res[w2][5];
         }
@@ -1477,7 +1515,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
         }
         C left = hi2 - lo2;
         while (left > 0) {
-          const uint32_t chunk = (uint32_t)min((C)64, left);
+          const uint32_t chunk = (uint32_t)min((C)TEAM_CHUNK, left);
           const uint32_t na = cc2 < (unsigned)TEAM_MAX_CHUNKS ? (uint32_t)t_nacc[cc2] : 0u;
           const uint32_t slot = (uint32_t)hs + (uint32_t)lane;
           const bool keep = (uint32_t)lane < na && (cands[slot].score >= max_aln_score - range);

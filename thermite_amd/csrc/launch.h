@@ -183,7 +183,7 @@ constexpr unsigned HEAVY_HITS = 8;  // reads with at least this many seed hits a
 // reads with at least this many hits are worked on by a whole workgroup (extend_kernel, TEAM): speculative chunks of hits
 constexpr unsigned TEAM_HITS = 256;
 constexpr int TEAM_WAVES = 16;
-constexpr unsigned TEAM_MAX_HITS = 200000;  // beyond that the team's per-chunk book does not fit: sequential path
+constexpr unsigned TEAM_MAX_HITS = 60000;   // beyond that the team's per-chunk book (16384 chunks of 4 hits, less one per SMEM) does not fit: sequential path
 // intron markers one alignment can carry in the register-resident kernel (LDS); an alignment across more
 // introns sends its read to the any-width kernel, whose marker list is sized by the longest transcript
 constexpr int FAST_MAX_YCLIPS = 64;

@@ -250,13 +250,19 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   const size_t trace_waves = std::max<size_t>((size_t)ext_blocks * 4, team_ok ? (size_t)a->n_cu * TEAM_WAVES : 0);
   HIPCHK(a, a->e_trace.ensure(trace_waves * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
   ep.trace_scratch = a->e_trace.as<unsigned long long>();
-  HIPCHK(a, launch_extend(ep, cpl, ext_blocks, s));
-  // reads with very many hits: a workgroup per read (speculative chunks of hits, kernels_extend.hip TEAM)
+  // reads with very many hits: a workgroup per read (speculative chunks of hits, kernels_extend.hip TEAM), on a second
+  // stream BESIDE the wave-per-read kernel: such reads are the long jobs of a batch, a launch behind the main kernel
+  // would put them on the critical path; launched first, so that its few workgroups find room
   if (team_ok) {
     ExtendParamsT<C> tp = ep;
     tp.list_only = 1;
-    HIPCHK(a, launch_extend(tp, cpl, a->n_cu, s, true));
+    HIPCHK(a, hipEventRecord(a->ev_fork, s));
+    HIPCHK(a, hipStreamWaitEvent(a->stream2, a->ev_fork, 0));
+    HIPCHK(a, launch_extend(tp, cpl, a->n_cu, a->stream2, true));
+    HIPCHK(a, hipEventRecord(a->ev_join, a->stream2));
   }
+  HIPCHK(a, launch_extend(ep, cpl, ext_blocks, s));
+  if (team_ok) HIPCHK(a, hipStreamWaitEvent(s, a->ev_join, 0));
   // ---- slow class (and the fast kernel's retries) ----
   if (cls.n_slow || retry_possible) {
     const uint32_t sl_len = std::max(cls.slow_len, cls.fast_len), sl_bw = std::max(cls.slow_bw, cls.fast_bw);
