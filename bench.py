@@ -113,13 +113,16 @@ def main():
                          "that ship with the reference's data/ (copied to tests/golden/data)")
     ap.add_argument("--percent", type=float, default=None, help="override min_aln_score_percent (config 5: 0.574 at 150 bp = band +-64)")
     ap.add_argument("--wide", action="store_true", help="64-bit text coordinates inside the index (the path a GRCh38-sized text takes)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend; gloo + --one-device runs the N > 1 code path on a one-GPU box (tests)")
+    ap.add_argument("--one-device", action="store_true", help="every rank on device 0 (tests of the N > 1 path on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -132,9 +135,13 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
     from thermite_amd import capi, sharding, synth
 
@@ -214,7 +221,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -222,7 +229,7 @@ def main():
     cnt_local = np.zeros(capi.N_COUNTERS, np.uint64)
     for a in aligners:
         cnt_local += a.counters()
-    cnt = torch.from_numpy(cnt_local.astype(np.int64)).to(dev)
+    cnt = torch.from_numpy(cnt_local.astype(np.int64)).to(cdev)
     if world > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     cnt = cnt.cpu().numpy().astype(np.uint64)
@@ -292,12 +299,32 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         if world > 1:
-            tm = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt = float(tm.item())
         value_e2e = {"value": round(n_thr * per_thread * reads_this_rank * world / dt, 1), "unit": "reads/s",
                      "what": "host buffers in, host views out: H2D reads + all kernels + D2H alignments and op streams, "
                              "%d batches on %d aligners / host threads per GPU (transfers overlap kernels)" % (n_thr * per_thread, n_thr)}
+
+    # ---------------- two batches in flight (not `value`): step i + 1 is launched (another aligner, another HIP stream)
+    # before step i is waited for, so that the tail of one batch's extend kernel is filled by the other batch ----------------
+    value_two_in_flight = None
+    if NB >= 2 and not strong:
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(K + 1):
+            if i < K:
+                aligners[i % NB].run()
+            if i >= 1:
+                aligners[(i - 1) % NB].sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt = float(tm.item())
+        value_two_in_flight = {"value": round(K * reads_this_rank * world / dt, 1), "unit": "reads/s", "ms_per_step": round(dt / K * 1e3, 4),
+                               "what": "the same %d steps with two batches in flight per GPU (two aligners, two HIP streams)" % K}
 
     # ---------------- CPU baseline (rank 0, N = 1 only) ----------------
     cpu_baseline = None
@@ -348,6 +375,7 @@ def main():
             "roofline": roofline,
             "roofline_valu": roofline_valu,
             "value_e2e": value_e2e,
+            "value_two_in_flight": value_two_in_flight,
             "cpu_baseline": cpu_baseline,
             "counters": {k: c[k] for k in ("reads", "aligned", "unmapped", "alns", "exonic", "intronic", "intergenic",
                                            "smems", "hits", "swg_calls", "dp_cells")},

@@ -275,7 +275,7 @@ int32_t thm_build_suffix_array64(const uint8_t* text, uint64_t n, uint64_t* sa_o
  * that device. */
 int32_t thm_aligner_create(const thm_index*, const thm_align_opts*, int32_t device_id, thm_aligner** out);
 void thm_aligner_free(thm_aligner*);
-const char* thm_last_error(const thm_aligner*); /* NULL-safe: global last error when NULL */
+const char* thm_last_error(const thm_aligner*); /* NULL: the calling thread's last error from a call without an aligner */
 int32_t thm_aligner_set_opts(thm_aligner*, const thm_align_opts*);
 /* the aligner's hipStream_t, as void* (for events / ExternalStream) */
 void* thm_aligner_stream(thm_aligner*);

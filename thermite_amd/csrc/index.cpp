@@ -26,16 +26,11 @@
 
 namespace thm {
 
-static std::mutex g_err_mu;
-static std::string g_err;
-void set_global_error(const std::string& msg) {
-  std::lock_guard<std::mutex> g(g_err_mu);
-  g_err = msg;
-}
-const char* global_error_cstr() {
-  std::lock_guard<std::mutex> g(g_err_mu);
-  return g_err.c_str();
-}
+// last error of the calling thread (thm_last_error(NULL)): per thread, so that the parser, GPU and writer threads of
+// the file driver never read a string another thread is assigning
+static thread_local std::string g_err;
+void set_global_error(const std::string& msg) { g_err = msg; }
+const char* global_error_cstr() { return g_err.c_str(); }
 
 template <class C>
 bool verify_suffix_array(const uint8_t* text, uint64_t n, const C* sa) {
