@@ -117,7 +117,7 @@ def main():
                     help="process-group backend; gloo + --one-device runs the N > 1 code path on a one-GPU box (tests)")
     ap.add_argument("--one-device", action="store_true", help="every rank on device 0 (tests of the N > 1 path on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the extra figures (value_e2e, value_two_in_flight): profiling passes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -309,7 +309,7 @@ def main():
     # ---------------- two batches in flight (not `value`): step i + 1 is launched (another aligner, another HIP stream)
     # before step i is waited for, so that the tail of one batch's extend kernel is filled by the other batch ----------------
     value_two_in_flight = None
-    if NB >= 2 and not strong:
+    if not args.no_e2e and NB >= 2 and not strong:
         barrier()
         t1 = time.perf_counter()
         for i in range(K + 1):

@@ -110,7 +110,7 @@ if s1:
           "extend_wait_inst_share": e.get("wait_inst_share_of_wave_cycles"),
           "extend_valu_insts_per_read": round(e.get("SQ_INSTS_VALU", 0) / n_reads, 1),
           "extend_wait_any_share": e.get("wait_any_share_of_wave_cycles"),
-          "source": "profiles/r02/sq_counters_bench%s.json (rocprofv3 --pmc SQ_*; valu_busy = 4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)" % suffix}
+          "source": "profiles/r02/sq_counters_bench%s.json (rocprofv3 --pmc SQ_*; valu_busy = waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)" % suffix}
     json.dump(sq, open(os.path.join(ROOT, "profiles", "sq_counters.json"), "w"), indent=1)
     for k, d in summ.items():
         if "rocclr" not in k:
