@@ -570,6 +570,10 @@ __device__ unsigned long long emit_alignment(W& c, const PP& p, const uint8_t* p
   return off;
 }
 
+#ifndef THM_READ_RUN
+#define THM_READ_RUN 4
+#endif
+constexpr int READ_RUN = THM_READ_RUN;  // consecutive reads per queue atomic of the wave-per-read kernels
 constexpr int TEAM_MAX_CHUNKS = 16384;  // chunks a team keeps book of (reads beyond that stay with the sequential path)
 constexpr int TEAM_CHUNK = 4;           // hits per chunk of a team
 
@@ -720,7 +724,9 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
   unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
   int batch_fault = 0;
 
-  // Reads are handed out by atomic counters, one at a time.  Small chunks balance the waves
+  // Reads are handed out by atomic counters, READ_RUN consecutive reads at a time (the second to fourth read of a run
+  // start without the atomic's round trip, and their records and bases share cache lines with the first: 3.95 ->
+  // 3.89 ms).  Small chunks balance the waves
   // (the cost per read varies by orders of magnitude: repeats), but one hot word serves only ~88 M
   // returning atomics per second; so there are EXT_NQ counters on separate cache lines, each over
   // its own contiguous share of the batch, and a wave that finds its counter exhausted moves on to
@@ -743,9 +749,15 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
   const unsigned list_q = (GS ? EXT_NQ + 1 : EXT_NQ) * EXT_QSTRIDE;
   // (Issuing the atomic for the next read while the current one is worked on was tried: the pending return value
   // stays live across the whole hit loop and costs 400 bytes per lane of spills -- three times slower.)
+  unsigned pend_idx = 0, pend_n = 0;  // rest of the run of READ_RUN consecutive reads one queue atomic handed out
   for (;;) {
     bool from_heavy = false, got = false;
     unsigned idx = 0;
+    if (!TM && pend_n) {
+      idx = pend_idx++;
+      pend_n--;
+      got = true;
+    }
     if constexpr (TM) {
       // one read for the whole workgroup
       if (threadIdx.x == 0) t_ctl[0] = atomicAdd(p.queue + (EXT_NQ + 2) * EXT_QSTRIDE, 1u);
@@ -772,11 +784,13 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
     }
     while (!got && q_tried < EXT_NQ && n_total) {
       unsigned g = 0;
-      if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, 1u);
+      if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, (unsigned)READ_RUN);
       g = (unsigned)bcast_first((int)g);
       const unsigned lo = my_q * q_share, hi = min(lo + q_share, n_total);
       if (lo < hi && g < hi - lo) {
         idx = lo + g;
+        pend_idx = idx + 1;
+        pend_n = min((unsigned)READ_RUN - 1u, hi - lo - g - 1u);
         got = true;
         break;
       }
@@ -1138,6 +1152,8 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
             if (!genome_done) {
               gx = pth;
               genome_done = true;
+              // (asking before the genome extension, so that the two round trips run under it, was tried: the query's
+              // registers stay live across the DP loops -- 7 % slower)
               grid_begin<C>(eg, ix.exon_grid_off, ix.exon_grid, qs, qe);
             } else {
               if (!have_best || pth.score > best.score) {  // strictly better (:249)
@@ -1793,7 +1809,7 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
   }
   // register budget: MINW waves per SIMD.  Measured on the 32-bit-coordinate kernels (round 2, benchmark workload,
   // same box): one cell per lane 3.60 ms at 6 waves against 3.90 at 8 (560 bytes per lane of spills) and 3.96 at 4;
-  // two cells per lane 3.97 ms at 6 (80 VGPRs, 128 bytes of spills) against 4.02 at 5, 4.23 at 8, 4.64 at 4; wider
+  // two cells per lane 3.89 ms at 6 (80 VGPRs, 136 bytes of spills) against 3.96 at 5, 4.30 at 7 (72 VGPRs), 4.23 at 8, 4.64 at 4; wider
   // bands run at 4.  Tuning knob THM_EXT_MINW = 4 | 5 | 6 | 8 for the one- and two-cell kernels.  The
   // 64-bit-coordinate kernels carry more live state per hit and run at 4 waves per SIMD.
   static const int minw_env = [] {
