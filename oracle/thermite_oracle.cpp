@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <thread>
 #include <unordered_map>
 #include <utility>
@@ -977,17 +978,26 @@ std::vector<GenomeAlignment> align_read(const orc_index& index, const uint8_t* r
   Scoring scoring{-1, -1, 1, -1};
   SwgExtend swg(band_width, scoring);
 
+  // diagnostic for tools/tail_diag.py (ORC_TRACE_STATE=<min hits>): at which hits the loop-carried state moves
+  static const long trace_min = getenv("ORC_TRACE_STATE") ? atol(getenv("ORC_TRACE_STATE")) : 0;
+  const bool trace_state = trace_min > 0 && (long)mems.size() >= trace_min;
+  std::string trace_line;
+  usize hit_no = 0;
   for (const Mem& hit : mems) {
+    hit_no++;
     GenomeAlignment gx_aln = align_seed_hit(index, read.data(), read_len, hit, swg, band_width, (int32_t)x_drop, fault);
     if (!opts.intron_mode && gx_aln.aln_type != EXONIC) continue;
     int32_t sc = gx_aln.gx_aln.score;
     if (sc < opts.min_aln_score || sc < min_aln_score || sc < max_aln_score - range) continue;
     usize lim = sc < 0 ? 0 : sat_sub(read_len + opts.multimap_score_range, (usize)sc);
+    if (trace_state && (std::min(band_width, lim) != band_width || std::min(x_drop, lim) != x_drop || sc > max_aln_score))
+      trace_line += " " + std::to_string(hit_no) + ":" + std::to_string(sc);
     band_width = std::min(band_width, lim);
     x_drop = std::min(x_drop, lim);
     max_aln_score = std::max(max_aln_score, sc);
     gx_alns.push_back(std::move(gx_aln));
   }
+  if (trace_state) fprintf(stderr, "ORC_TRACE_STATE hits=%zu accepted=%zu state moved at (hit:score)%s\n", mems.size(), gx_alns.size(), trace_line.c_str());
   cnt.c[9] += swg.n_calls;
   cnt.c[10] += swg.n_cells;
   cnt.c[11] += swg.n_cols;

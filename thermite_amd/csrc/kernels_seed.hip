@@ -755,7 +755,8 @@ __global__ __launch_bounds__(256) void plan_kernel(PlanParams p) {
     p.read_n_alns[r] = 0;
     p.read_op_bytes[r] = 0;
   }
-  const bool team = fast && p.team_ok && hits >= TEAM_HITS && hits <= TEAM_MAX_HITS;
+  const uint64_t team_thr = min((uint64_t)TEAM_HITS, max((uint64_t)TEAM_MIN_HITS, *p.total_hits / max(p.team_div, 1u)));
+  const bool team = fast && p.team_ok && hits >= team_thr && hits <= TEAM_MAX_HITS;
   block_append(fast && !team && hits >= HEAVY_HITS, r, p.heavy, &p.counts[2]);
   block_append(slow, r, p.slow, &p.counts[5]);
   block_append(team, r, p.team, &p.counts[7]);

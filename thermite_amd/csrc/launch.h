@@ -100,8 +100,10 @@ struct PlanParams {
   uint32_t slow_max_len;  // longer ones up to this length in the any-width kernel; beyond: THM_ERR_UNSUPPORTED
   unsigned long long* heavy;
   unsigned long long* slow;
-  unsigned long long* team;    // reads with >= TEAM_HITS hits (counts[7]) when team_ok
+  unsigned long long* team;    // reads with >= the team threshold of hits (counts[7]) when team_ok
   uint32_t team_ok;
+  const uint64_t* total_hits;  // hits of the whole batch (the last element of the scan of read_hits)
+  uint32_t team_div;           // team threshold = clamp(total_hits / team_div, TEAM_MIN_HITS, TEAM_HITS); see TEAM_HITS
   unsigned long long* counts;  // work_counts of the seed stage
   int32_t* read_status;
   uint32_t* read_n_alns;       // zeroed for unsupported reads
@@ -180,8 +182,16 @@ struct Cand {
 constexpr unsigned EXT_NQ = 8, EXT_QSTRIDE = 64;
 constexpr size_t QUEUE_BYTES = (EXT_NQ + 3) * EXT_QSTRIDE * 4;  // + the counters of the heavy-read list, the slow list and the team list
 constexpr unsigned HEAVY_HITS = 8;  // reads with at least this many seed hits are scheduled first
-// reads with at least this many hits are worked on by a whole workgroup (extend_kernel, TEAM): speculative chunks of hits
+// Reads with very many hits are worked on by a whole workgroup (extend_kernel, TEAM): speculative chunks of hits.
+// Which reads: a wave takes ~20 us per hit (a chain of dependent memory round trips) whatever else runs, the whole
+// machine ~4.5 ns per hit of a batch (256 CUs) -- a read whose hits take one wave longer than the rest of the batch
+// takes the machine is the tail of the launch (measured, tools/tail_diag.py: the benchmark's batches of ~815 k hits
+// finish in 3.65 ms without their reads of >= 64 hits, in 3.9 - 5.0 ms with them, set by the one longest read of 190 -
+// 280 hits).  So the threshold follows the batch: total_hits / (TEAM_DIV_PER_CU x #CU), ~145 hits for the benchmark's
+// batches, within [TEAM_MIN_HITS, TEAM_HITS].
 constexpr unsigned TEAM_HITS = 256;
+constexpr unsigned TEAM_MIN_HITS = 32;
+constexpr unsigned TEAM_DIV_PER_CU = 22;
 constexpr int TEAM_WAVES = 16;
 constexpr unsigned TEAM_MAX_HITS = 60000;   // beyond that the team's per-chunk book (16384 chunks of 4 hits, less one per SMEM) does not fit: sequential path
 // intron markers one alignment can carry in the register-resident kernel (LDS); an alignment across more

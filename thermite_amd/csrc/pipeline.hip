@@ -250,19 +250,24 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   const size_t trace_waves = std::max<size_t>((size_t)ext_blocks * 4, team_ok ? (size_t)a->n_cu * TEAM_WAVES : 0);
   HIPCHK(a, a->e_trace.ensure(trace_waves * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
   ep.trace_scratch = a->e_trace.as<unsigned long long>();
-  // reads with very many hits: a workgroup per read (speculative chunks of hits, kernels_extend.hip TEAM), on a second
-  // stream BESIDE the wave-per-read kernel: such reads are the long jobs of a batch, a launch behind the main kernel
-  // would put them on the critical path; launched first, so that its few workgroups find room
+  // reads with very many hits: a workgroup per read (speculative chunks of hits, kernels_extend.hip TEAM) BESIDE the
+  // wave-per-read kernel: such reads are the long jobs of a batch, a launch behind the main kernel would put them on
+  // the critical path.  A team workgroup needs a whole CU's registers, so it must be placed before the persistent
+  // waves of the main kernel fill the machine: the team kernel goes first on this stream, the main kernel on the second
+  // stream behind an event (the event's latency is the team's head start; the other way round the team kernel started
+  // 10 us late and waited for the main kernel to drain -- rocprofv3 kernel trace, tools/overlap_trace.py).
   if (team_ok) {
     ExtendParamsT<C> tp = ep;
     tp.list_only = 1;
     HIPCHK(a, hipEventRecord(a->ev_fork, s));
+    HIPCHK(a, launch_extend(tp, cpl, a->n_cu, s, true));
     HIPCHK(a, hipStreamWaitEvent(a->stream2, a->ev_fork, 0));
-    HIPCHK(a, launch_extend(tp, cpl, a->n_cu, a->stream2, true));
+    HIPCHK(a, launch_extend(ep, cpl, ext_blocks, a->stream2));
     HIPCHK(a, hipEventRecord(a->ev_join, a->stream2));
+    HIPCHK(a, hipStreamWaitEvent(s, a->ev_join, 0));
+  } else {
+    HIPCHK(a, launch_extend(ep, cpl, ext_blocks, s));
   }
-  HIPCHK(a, launch_extend(ep, cpl, ext_blocks, s));
-  if (team_ok) HIPCHK(a, hipStreamWaitEvent(s, a->ev_join, 0));
   // ---- slow class (and the fast kernel's retries) ----
   if (cls.n_slow || retry_possible) {
     const uint32_t sl_len = std::max(cls.slow_len, cls.fast_len), sl_bw = std::max(cls.slow_bw, cls.fast_bw);
@@ -336,6 +341,15 @@ int enqueue_run(thm_aligner* a) {
   {
     const int cpl_f = std::max(1, (int)((2 * cls.fast_bw + 1 + 63) / 64));
     pp.team_ok = (cpl_f <= 2 && extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl_f) / 4 * TEAM_WAVES <= EXTEND_LDS_LIMIT) ? 1u : 0u;
+  }
+  pp.total_hits = a->s_cand_off.as<uint64_t>() + n;
+  {
+    static const unsigned div_env = [] {
+      const char* e = getenv("THM_TEAM_DIV_PER_CU");  // tuning knob
+      const int v = e ? atoi(e) : 0;
+      return v > 0 ? (unsigned)v : TEAM_DIV_PER_CU;
+    }();
+    pp.team_div = div_env * (uint32_t)std::max(a->n_cu, 1);
   }
   pp.counts = a->s_work_counts.as<unsigned long long>();
   pp.read_status = a->r_status.as<int32_t>();
