@@ -1732,12 +1732,28 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
   for (uint32_t t = 0; t < n; t++) {
     const Cand cd = cands[la[t]];
     if (a0 + t >= p.alns_cap || o + cd.ops_len + cd.tx_ops_len > p.ops_cap) return;  // never without a fault; keeps every store in bounds
-    #pragma unroll 1
-    for (uint32_t b = (uint32_t)sub; b < cd.ops_len; b += 16) p.ops[o + b] = p.cand_ops[cd.ops_off + b];
+    // 64 bytes per step of the 16 lanes, the four loads of a lane in flight together (a byte at a time would be one
+    // memory round trip per 16 bytes)
+    auto copy_ops = [&](const uint8_t* src, uint8_t* dst, uint32_t len) {
+      #pragma unroll 1
+      for (uint32_t b0 = 0; b0 < len; b0 += 64) {
+        uint8_t v[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t b = b0 + (uint32_t)sub + 16u * (uint32_t)k;
+          v[k] = (b < len) ? src[b] : (uint8_t)0;
+        }
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t b = b0 + (uint32_t)sub + 16u * (uint32_t)k;
+          if (b < len) dst[b] = v[k];
+        }
+      }
+    };
+    copy_ops(p.cand_ops + cd.ops_off, p.ops + o, cd.ops_len);
     const uint64_t go = o;
     o += cd.ops_len;
-    #pragma unroll 1
-    for (uint32_t b = (uint32_t)sub; b < cd.tx_ops_len; b += 16) p.ops[o + b] = p.cand_ops[cd.tx_ops_off + b];
+    copy_ops(p.cand_ops + cd.tx_ops_off, p.ops + o, cd.tx_ops_len);
     const uint64_t to = o;
     o += cd.tx_ops_len;
     if (sub == 0) {
@@ -1808,10 +1824,12 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
     return hipErrorInvalidValue;
   }
   // register budget: MINW waves per SIMD.  Measured on the 32-bit-coordinate kernels (round 2, benchmark workload,
-  // same box): one cell per lane 3.60 ms at 6 waves against 3.90 at 8 (560 bytes per lane of spills) and 3.96 at 4;
-  // two cells per lane 3.89 ms at 6 (80 VGPRs, 136 bytes of spills) against 3.96 at 5, 4.30 at 7 (72 VGPRs), 4.23 at 8, 4.64 at 4; wider
-  // bands run at 4.  Tuning knob THM_EXT_MINW = 4 | 5 | 6 | 8 for the one- and two-cell kernels.  The
-  // 64-bit-coordinate kernels carry more live state per hit and run at 4 waves per SIMD.
+  // same box).  One cell per lane: 3.67 ms at 6 waves against 3.78 at 5, 3.90 at 8 (560 bytes per lane of spills), 3.96
+  // at 4 -> 6.  Two cells per lane: 3.89 ms at 6 (80 VGPRs, 136 bytes per lane of spills), 3.96 at 5 (96 VGPRs, 76 bytes),
+  // 4.30 at 7, 4.23 at 8, 4.64 at 4; but at 6 waves the spills move 3.2 GB per 500 k-read launch through the memory
+  // system (rocprofv3 FETCH_SIZE / WRITE_SIZE) against 1.2 GB at 5 and 0.53 GB of algorithmic bytes: 1 % of throughput
+  // for 2.6x less traffic -> 5.  Wider bands run at 4.  Tuning knob THM_EXT_MINW = 4 | 5 | 6 | 8 for the one- and
+  // two-cell kernels.  The 64-bit-coordinate kernels carry more live state per hit and run at 4 waves per SIMD.
   static const int minw_env = [] {
     const char* e = getenv("THM_EXT_MINW");
     const int v = e ? atoi(e) : 0;
@@ -1827,10 +1845,11 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
       default: return hipErrorInvalidValue;
     }
   } else {
-    const int minw = minw_env ? minw_env : (cpl <= 2 ? 6 : 4);
+    const int minw = minw_env ? minw_env : (cpl == 1 ? 6 : cpl == 2 ? 5 : 4);
     switch (cpl) {
       case 1:
         if (minw == 4) return go(dev::extend_kernel<C, 1, 4>);
+        if (minw == 5) return go(dev::extend_kernel<C, 1, 5>);
         if (minw == 6) return go(dev::extend_kernel<C, 1, 6>);
         return go(dev::extend_kernel<C, 1, 8>);
       case 2:

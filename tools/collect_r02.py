@@ -99,10 +99,11 @@ if s1:
             d["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 4)
         summ[k] = d
     json.dump(summ, open(os.path.join(dst, "sq_counters_bench%s.json" % suffix), "w"), indent=1)
-    e = max((v for k, v in summ.items() if k.startswith("extend_kernel")), key=lambda v: v.get("SQ_INSTS_VALU", 0))
+    ek, e = max(((k, v) for k, v in summ.items() if k.startswith("extend_kernel")), key=lambda kv: kv[1].get("SQ_INSTS_VALU", 0))
     # SIMD view: a SIMD issues one VALU instruction at a time; with W waves resident per SIMD its vector ALU is busy
-    # W x (per-wave VALU share) of the time.  W = 6 for the two-cells-per-lane extend kernel (80 VGPRs).
-    W = 6
+    # W x (per-wave VALU share) of the time.  W = the kernel's launch bound (third template argument: waves per SIMD
+    # its register budget is compiled for).
+    W = int(ek.split("<")[1].split(">")[0].split(",")[2])
     sq = {"round": 2, "reads_per_gpu": n_reads, "ref_len": 46709983, "opts": "ci",
           "extend_valu_busy_frac": round(min(1.0, W * e.get("valu_issue_share_of_wave_cycles", 0)), 4),
           "extend_waves_per_simd": W,
