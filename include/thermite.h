@@ -208,7 +208,9 @@ enum {
   THM_CNT_DP_CELLS = 10,
   THM_CNT_DP_COLS = 11,
   THM_CNT_OP_BYTES = 12,
-  THM_CNT_WINDOW_BYTES = 13, /* reference / transcript window bytes staged for extension */
+  THM_CNT_WINDOW_BYTES = 13, /* window bytes of every target extended: the genome window (src/aligner.rs:212-215) and, per
+                                transcript, [seed - (L + bw), seed end + L + bw + 1) -- the term of SURVEY.md 8(d)'s
+                                algorithmic bytes; counted whether or not the kernel had to stage the window */
   THM_N_COUNTERS = 16
 };
 

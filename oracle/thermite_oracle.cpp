@@ -93,6 +93,7 @@ struct SwgExtend {
   usize max_band_width;
   // instrumentation (not in the reference)
   usize n_cells = 0, n_cols = 0, n_calls = 0, n_phase1_breaks = 0;
+  usize n_win_bytes = 0;  // reference / transcript window bytes of the targets extended (bookkeeping, not the reference's)
   bool fault = false;  // the reference would have panicked (out-of-bounds trace)
 
   // src/swg.rs:17-26
@@ -855,6 +856,7 @@ GenomeAlignment align_seed_hit(const orc_index& index, const uint8_t* read, usiz
     usize seq_start = std::max(sat_sub(hit.ref_idx, read_len + band_width), aln_ref.start_idx);
     usize seq_end = std::min(hit.ref_idx + hit.len + read_len + band_width, aln_ref.end_idx - 1);
     std::vector<uint8_t> ref_seq = index.seq_slice(seq_start, seq_end);
+    swg.n_win_bytes += seq_end - seq_start;
     Mem rel = hit;
     rel.ref_idx -= seq_start;
     gx_aln = extend_left_right(ref_seq.data(), ref_seq.size(), rel, read, read_len, swg, band_width, x_drop);
@@ -874,6 +876,10 @@ GenomeAlignment align_seed_hit(const orc_index& index, const uint8_t* read, usiz
       *fault = true;
       break;
     }
+    // the part of the transcript the two extensions can reach (the reference passes the whole tx.seq and lets
+    // extend_left_right slice it, :360-375): [seed - (L + bw), seed end + L + bw + 1), the term 2(L+bw)+len of SURVEY.md 8(d)
+    swg.n_win_bytes += std::min(tx.seq_len, tx_seed.ref_idx + tx_seed.len + read_len + band_width + 1) -
+                       sat_sub(tx_seed.ref_idx, read_len + band_width);
     extend_seed_match(tx.seq, tx.seq_len, tx_seed, read, read_len);
     Alignment tx_aln = extend_left_right(tx.seq, tx.seq_len, tx_seed, read, read_len, swg, band_width, x_drop);
     int32_t tx_aln_score = tx_aln.score;
@@ -999,6 +1005,7 @@ std::vector<GenomeAlignment> align_read(const orc_index& index, const uint8_t* r
   }
   if (trace_state) fprintf(stderr, "ORC_TRACE_STATE hits=%zu accepted=%zu state moved at (hit:score)%s\n", mems.size(), gx_alns.size(), trace_line.c_str());
   cnt.c[9] += swg.n_calls;
+  cnt.c[13] += swg.n_win_bytes;
   cnt.c[10] += swg.n_cells;
   cnt.c[11] += swg.n_cols;
   if (swg.fault) *fault = true;

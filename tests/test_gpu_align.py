@@ -75,7 +75,7 @@ def check_align(w, bases, off, opts, n_threads=8):
     assert g.n_failed == 0 and g.status is None
     assert_batch_equal(g, r)
     c = a.counters()
-    assert np.array_equal(c[:10], r.counters[:10]) and c[12] == r.counters[12], (c[:13], r.counters[:13])
+    assert np.array_equal(c[:10], r.counters[:10]) and c[12] == r.counters[12] and c[13] == r.counters[13], (c[:14], r.counters[:14])
     assert c[10] <= r.counters[10] and c[11] <= r.counters[11]  # DP work: exact early exit computes fewer cells
     a.close()
     return g

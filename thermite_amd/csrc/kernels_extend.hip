@@ -1034,10 +1034,11 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
               by_coords = ge.prev_end <= qs && t_q == q && t_len == len && gmemo.R.broke && gmemo.Lt.broke &&
                           hr + (S)(len + gmemo.R.jmax) <= xe && hr - (S)gmemo.Lt.jmax >= xs;
               int w0 = 0;
-              if (!by_coords) {
               // window of the transcript around the lifted seed
               const int ws = (tr_ > L + bw) ? tr_ - (L + bw) : 0;
               const int we = min(tlen, tr_ + t_len + L + bw + 1);
+              if (by_coords) c.winbytes += (unsigned)(we - ws);  // THM_CNT_WINDOW_BYTES counts the target's window, staged or not
+              if (!by_coords) {
               w0 = stage_window(c, c.win, ix.tx_seq + tx.seq_off, ws, we);
               // extend_seed_match (src/aligner.rs:410-426): ballots of the first mismatch
               {
