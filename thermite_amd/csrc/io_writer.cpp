@@ -540,21 +540,29 @@ bool format_range_bam(const Ctx& c, const std::vector<int32_t>& sq_of_name, uint
 bool bgzf_compress(const char* p, size_t n, std::string& out) {
   constexpr size_t BLOCK = 0xff00;
   std::vector<unsigned char> buf(compressBound(BLOCK) + 64);
+  // one deflate state for all blocks of the call (deflateInit2 allocates and clears ~270 KB: per 64 KiB block that is
+  // a tenth of the work), reset between the members
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  bool ok = true;
   for (size_t off = 0; off < n || (n == 0 && off == 0); off += BLOCK) {
     const size_t len = std::min(BLOCK, n - off);
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    if (off && deflateReset(&zs) != Z_OK) {
+      ok = false;
+      break;
+    }
     zs.next_in = (Bytef*)(p + off);
     zs.avail_in = (uInt)len;
     zs.next_out = buf.data();
     zs.avail_out = (uInt)buf.size();
     const int rc = deflate(&zs, Z_FINISH);
     const size_t clen = zs.total_out;
-    deflateEnd(&zs);
-    if (rc != Z_STREAM_END) return false;
     const size_t bsize = clen + 25;  // whole block size - 1
-    if (bsize > 0xffff) return false;
+    if (rc != Z_STREAM_END || bsize > 0xffff) {
+      ok = false;
+      break;
+    }
     const unsigned char hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
                                    (unsigned char)(bsize & 0xff), (unsigned char)(bsize >> 8)};
     out.append((const char*)hdr, 18);
@@ -563,7 +571,8 @@ bool bgzf_compress(const char* p, size_t n, std::string& out) {
     le32(out, (uint32_t)len);
     if (n == 0) break;
   }
-  return true;
+  deflateEnd(&zs);
+  return ok;
 }
 
 }  // namespace
