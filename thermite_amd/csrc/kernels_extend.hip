@@ -573,10 +573,6 @@ __device__ unsigned long long emit_alignment(W& c, const PP& p, const uint8_t* p
 #ifndef THM_READ_RUN
 #define THM_READ_RUN 4
 #endif
-#ifndef THM_PRIO_HITS
-#define THM_PRIO_HITS 32
-#endif
-constexpr unsigned PRIO_HITS = THM_PRIO_HITS;  // heavy reads with at least this many hits run at raised wave priority
 constexpr int READ_RUN = THM_READ_RUN;  // consecutive reads per queue atomic of the wave-per-read kernels
 constexpr int TEAM_MAX_CHUNKS = 16384;  // chunks a team keeps book of (reads beyond that stay with the sequential path)
 constexpr int TEAM_CHUNK = 4;           // hits per chunk of a team
@@ -631,7 +627,7 @@ __host__ __device__ inline SlowLayout slow_layout(uint32_t max_read_len, uint32_
 // kernel (band in tiles, wave-private buffers in global memory): the slow path for reads whose band or length
 // exceeds what LDS and registers hold.  MINW: waves per SIMD the register budget is set for.
 //
-// TEAM > 0: the kernel for reads with very many seed hits (pack_reads_kernel lists them).  A workgroup of
+// TEAM > 0: the kernel for reads with very many seed hits (plan_kernel lists them).  A workgroup of
 // TEAM wavefronts works on ONE read at a time.  The hits of a read must be taken in order because band, X-drop
 // and best score are carried from hit to hit (src/aligner.rs:143-175) -- but they change only when a hit beats the
 // best score so far, which happens a handful of times per read, early.  So the hits are cut into the chunks of
@@ -642,7 +638,7 @@ __host__ __device__ inline SlowLayout slow_layout(uint32_t max_read_len, uint32_
 // them are redone in the next round.  Exact: every hit that is kept was extended under exactly the band, X-drop
 // and threshold the sequential loop would have used.  Speed-up on a read whose state has settled: TEAM-fold.
 template <class C, int CPL, int MINW, int TEAM = 0>
-__global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) void extend_kernel(ExtendParamsT<C> p_by_value) {
+__global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) void extend_kernel(ExtendParamsT<C> p_by_value) {
   typedef typename CoordTraits<C>::S S;
   constexpr bool GS = (CPL == 0);
   constexpr bool TM = TEAM > 0;
@@ -720,17 +716,15 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
 #endif
 
 #ifdef THM_TIMELINE
-  // diagnosis build (tools/timeline.py): when do the waves of the wave-per-read kernel run out of work?
+  // diagnosis build (tools/timeline.py): when do the waves of the wave-per-read kernel run out of work, and how long do
+  // reads take?
   const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
   unsigned long long tl_last = tl_start;
   unsigned tl_last_hits = 0, tl_reads = 0, tl_tx = 0;
-  unsigned long long tl_bins[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_longest = 0;
+  unsigned long long tl_longest = 0;
   auto tl_close = [&](unsigned long long now) {  // the read that started at tl_last ends now
     if (!tl_reads) return;
     const unsigned long long d = now - tl_last;  // 10 ns units
-    int b = 0;
-    for (unsigned long long lim = 2500; b < 7 && d >= lim; lim *= 2) b++;  // < 25 us, < 50, ..., < 1.6 ms, more
-    tl_bins[b] += d;
     const unsigned long long key = (d << 32) | ((unsigned long long)min(tl_tx, 65535u) << 16) | tl_last_hits;
     if (key > tl_longest) tl_longest = key;
   };
@@ -744,16 +738,19 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
   unsigned long long k_cells = 0, k_cols = 0, k_calls = 0, k_win = 0;
   int batch_fault = 0;
 
-  // Records (schedule order: launch.h, PackParamsT) are handed out by atomic counters, READ_RUN consecutive records at
-  // a time (the second to fourth of a run start without the atomic's round trip: 3.95 -> 3.89 ms).  Small chunks
-  // balance the waves (the cost per read varies by orders of magnitude: repeats), but one hot word serves only ~88 M
-  // returning atomics per second; so there are EXT_NQ counters on separate cache lines, counter q handing out the
-  // runs q, q + EXT_NQ, ... of the schedule, and a wave that finds its counter exhausted tries the others once.
+  // Reads are handed out by atomic counters, READ_RUN consecutive reads at a time (the second to fourth read of a run
+  // start without the atomic's round trip, and their records and bases share cache lines with the first: 3.95 ->
+  // 3.89 ms).  Small chunks balance the waves
+  // (the cost per read varies by orders of magnitude: repeats), but one hot word serves only ~88 M
+  // returning atomics per second; so there are EXT_NQ counters on separate cache lines, each over
+  // its own contiguous share of the batch, and a wave that finds its counter exhausted moves on to
+  // the next one.
   const bool list_only = GS || p.list_only != 0;
   const unsigned n_total = list_only ? 0u : (unsigned)p.reads.n_reads;
+  const unsigned q_share = (n_total + EXT_NQ - 1) / EXT_NQ;
   unsigned my_q = wave_global % EXT_NQ, q_tried = 0;
   // Longest jobs first: reads with many seed hits (repeats; up to a few hundred hits, i.e.
-  // milliseconds, against ~50 us for a typical read) are listed by pack_reads_kernel and handed
+  // milliseconds, against ~50 us for a typical read) are listed by plan_kernel and handed
   // out before everything else, one per wave; left in input order the last ones would start near
   // the end of the batch and the whole grid would wait for them (a quarter of the kernel's time
   // on the benchmark workload).  The any-width kernel works from its list alone.
@@ -801,14 +798,13 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
     }
     while (!got && q_tried < EXT_NQ && n_total) {
       unsigned g = 0;
-      if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, 1u);
+      if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, (unsigned)READ_RUN);
       g = (unsigned)bcast_first((int)g);
-      // run number g of counter q is run g * EXT_NQ + q of the schedule: all counters move through it together
-      const unsigned long long pos0 = ((unsigned long long)g * EXT_NQ + my_q) * (unsigned)READ_RUN;
-      if (pos0 < n_total) {
-        idx = (unsigned)pos0;
+      const unsigned lo = my_q * q_share, hi = min(lo + q_share, n_total);
+      if (lo < hi && g < hi - lo) {
+        idx = lo + g;
         pend_idx = idx + 1;
-        pend_n = (unsigned)min((unsigned long long)READ_RUN - 1ull, (unsigned long long)n_total - pos0 - 1ull);
+        pend_n = min((unsigned)READ_RUN - 1u, hi - lo - g - 1u);
         got = true;
         break;
       }
@@ -818,7 +814,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
     if (!got) break;
     // everything needed to start on the read, in one scalar load (launch.h, ReadRecT)
     const ReadRecT<C> rec = uload(&p.read_recs[idx]);
-    // not this launch's read: the slow class (and reads beyond every class) are listed by pack_reads_kernel
+    // not this launch's read: the slow class (and reads beyond every class) are listed by plan_kernel
     if (rec.len > p.max_read_len) continue;
     const uint64_t r0 = rec.base_off;
     const int L = (int)rec.len;
@@ -856,14 +852,6 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
       tl_reads++;
     }
 #endif
-    // A read with many hits is one wave's serial work (~19 us per hit on an idle SIMD, ~30 us when four other waves
-    // compete for the SIMD's issue slots): the longest of them end the launch.  Their waves get the issue priority.
-    if (!TM) {
-      if (from_heavy && n_hits_cap >= (uint64_t)PRIO_HITS)
-        __builtin_amdgcn_s_setprio(3);
-      else
-        __builtin_amdgcn_s_setprio(0);
-    }
     uint32_t n_acc = 0;
     unsigned acc_bytes = 0;  // op bytes and type of the most recent accepted candidate
     int acc_type = 0;
@@ -1358,7 +1346,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
       break;
     } else {
       // ---- end of a round: which chunks are valid? ----
-      if (t_total > (unsigned)TEAM_MAX_CHUNKS) c.fault |= FAULT_INTERNAL;  // pack_reads_kernel keeps such reads away from the team
+      if (t_total > (unsigned)TEAM_MAX_CHUNKS) c.fault |= FAULT_INTERNAL;  // plan_kernel keeps such reads away from the team
       const bool active = my_chunk < t_total;
       const bool changed = active && (band_width != st_bw || x_drop != st_xd || max_aln_score != st_max);
       if (lane == 0) {
@@ -1434,7 +1422,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
       c.fault &= ~FAULT_CONTRACT;
       n_acc = 0;
       if (lead && lane == 0) {
-        p.read_status[rec.read_idx] = THM_ERR_OUT_OF_CONTRACT;
+        p.read_status[idx] = THM_ERR_OUT_OF_CONTRACT;
         atomicAdd(p.n_contract, 1ull);
       }
     }
@@ -1694,8 +1682,8 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
     const unsigned long long tf2 = __builtin_amdgcn_s_memtime();
 #endif
     if (lead && lane == 0) {
-      p.read_n_alns[rec.read_idx] = nres;
-      p.read_op_bytes[rec.read_idx] = opb;
+      p.read_n_alns[idx] = nres;
+      p.read_op_bytes[idx] = opb;
     }
 #ifdef THM_PROF_FINAL
     {
@@ -1727,9 +1715,9 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 4 : MINW) vo
 #ifdef THM_TIMELINE
   if (!TM && !GS && lane == 0 && p.prof && tl_reads) {
     const unsigned long long tl_end = __builtin_amdgcn_s_memrealtime();
-    atomicMax(&p.prof[0], ~tl_start);                              // earliest start
-    atomicMax(&p.prof[1], ~tl_end);                                // first wave to leave
-    atomicMax(&p.prof[2], tl_end);                                 // last wave to leave
+    atomicMax(&p.prof[0], ~tl_start);  // earliest start
+    atomicMax(&p.prof[1], ~tl_end);    // first wave to leave (the work counters ran dry)
+    atomicMax(&p.prof[2], tl_end);     // last wave to leave
     atomicMax(&p.prof[3], (tl_end << 20) | min((tl_end - tl_last) / 100ull, 1048575ull));  // ... and the duration (us) of its last read
     tl_close(tl_end);
     atomicMax(&p.prof[4], tl_longest);  // the longest read: duration << 32 | transcript targets << 16 | hits

@@ -737,81 +737,56 @@ __global__ __launch_bounds__(256) void seed_select_thread_kernel(SeedParamsT<C> 
   }
 }
 
-// position among the threads of the workgroup with `flag`, counted on from an atomic counter: one atomic per
-// 256-thread workgroup (every thread must call it; valid for the threads with `flag`)
-__device__ __forceinline__ unsigned long long block_rank(bool flag, unsigned long long* count) {
-  __shared__ unsigned w_cnt[4];
-  __shared__ unsigned long long b_base;
-  const unsigned long long m = __ballot(flag);
-  const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
-  if (lane == 0) w_cnt[wv] = (unsigned)__popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned total = w_cnt[0] + w_cnt[1] + w_cnt[2] + w_cnt[3];
-    b_base = total ? atomicAdd(count, (unsigned long long)total) : 0ull;
-  }
-  __syncthreads();
-  unsigned before = 0;
-  for (int w = 0; w < wv; w++) before += w_cnt[w];
-  const unsigned long long r = b_base + before + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-  __syncthreads();
-  return r;
-}
-
-// After the seed stage, thread per read: the record the extend kernel starts a read from (launch.h, ReadRecT), placed
-// in schedule order (launch.h, PackParamsT), and the extend stage's lists: reads of the fast class with many seed hits
-// (longest jobs first), the team's reads, reads of the slow class (band or length beyond the register-resident
-// kernels), and the status of reads no kernel takes.
-template <class C>
-__global__ __launch_bounds__(256) void pack_reads_kernel(PackParamsT<C> p) {
-  const PlanParams& pl = p.plan;
+// After the seed stage: the extend stage's lists.  Reads of the fast class with many seed hits (longest
+// jobs first), reads of the slow class (band or length beyond the register-resident kernels), and the
+// status of reads no kernel takes.
+__global__ __launch_bounds__(256) void plan_kernel(PlanParams p) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const bool active = r < p.n_reads;
-  ReadRecT<C> rec;
-  rec.base_off = rec.smem_off = rec.cand_off = 0;
-  rec.len = rec.smem_cnt = rec.n_hits = 0;
-  rec.qpos0 = rec.len0 = 0;
-  rec.lo0 = rec.hi0 = rec.sa0 = 0;
-  rec.read_idx = (uint32_t)r;
   uint64_t L = 0, hits = 0;
   if (active) {
-    const uint64_t b0 = p.offsets[r];
-    L = p.offsets[r + 1] - b0;
-    rec.base_off = b0;
-    rec.len = L > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)L;
-    rec.smem_off = p.read_smem_off[r];
-    rec.smem_cnt = p.read_smem_cnt[r];
-    const uint64_t c0 = p.read_cand_off[r];
-    hits = p.read_cand_off[r + 1] - c0;
-    rec.cand_off = c0;
-    rec.n_hits = hits > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hits;
-    if (rec.smem_cnt > 0 && *p.fault_seed == 0) {  // after a pool overflow the runs are incomplete (the batch is replayed)
-      const SmemT<C> sm = p.smems[rec.smem_off];
-      rec.qpos0 = sm.qpos;
-      rec.len0 = sm.len;
-      rec.lo0 = sm.lo;
-      rec.hi0 = sm.hi;
-      if (sm.hi > sm.lo) rec.sa0 = p.sa[sm.hi - 1];
-    }
+    L = p.offsets[r + 1] - p.offsets[r];
+    hits = p.read_hits[r];
   }
-  const bool fast = active && L <= pl.fast_max_len;
-  const bool slow = active && !fast && L <= pl.slow_max_len;
+  const bool fast = active && L <= p.fast_max_len;
+  const bool slow = active && !fast && L <= p.slow_max_len;
   if (active && !fast && !slow) {
-    pl.read_status[r] = THM_ERR_UNSUPPORTED;
-    pl.read_n_alns[r] = 0;
-    pl.read_op_bytes[r] = 0;
+    p.read_status[r] = THM_ERR_UNSUPPORTED;
+    p.read_n_alns[r] = 0;
+    p.read_op_bytes[r] = 0;
   }
-  // schedule position: cheap reads from the back, everything else from the front
-  const bool light = SCHED_LIGHT_LAST && fast && (hits == 0 || (hits == 1 && rec.smem_cnt == 1 && (uint64_t)rec.len0 == L));
-  const unsigned long long front = block_rank(active && !light, &pl.counts[8]);
-  const unsigned long long back = block_rank(active && light, &pl.counts[9]);
-  const unsigned long long pos = light ? p.n_reads - 1 - back : front;
-  if (active) p.recs[pos] = rec;
-  const uint64_t team_thr = min((uint64_t)TEAM_HITS, max((uint64_t)TEAM_MIN_HITS, *pl.total_hits / max(pl.team_div, 1u)));
-  const bool team = fast && pl.team_ok && hits >= team_thr && hits <= TEAM_MAX_HITS;
-  block_append(fast && !team && hits >= HEAVY_HITS, pos, pl.heavy, &pl.counts[2]);
-  block_append(slow, pos, pl.slow, &pl.counts[5]);
-  block_append(team, pos, pl.team, &pl.counts[7]);
+  const uint64_t team_thr = min((uint64_t)TEAM_HITS, max((uint64_t)TEAM_MIN_HITS, *p.total_hits / max(p.team_div, 1u)));
+  const bool team = fast && p.team_ok && hits >= team_thr && hits <= TEAM_MAX_HITS;
+  block_append(fast && !team && hits >= HEAVY_HITS, r, p.heavy, &p.counts[2]);
+  block_append(slow, r, p.slow, &p.counts[5]);
+  block_append(team, r, p.team, &p.counts[7]);
+}
+
+// One record per read for the extend kernel (launch.h, ReadRecT): thread per read
+template <class C>
+__global__ __launch_bounds__(256) void pack_reads_kernel(PackParamsT<C> p) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= p.n_reads) return;
+  ReadRecT<C> rec;
+  const uint64_t b0 = p.offsets[r], L = p.offsets[r + 1] - b0;
+  rec.base_off = b0;
+  rec.len = L > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)L;
+  rec.smem_off = p.read_smem_off[r];
+  rec.smem_cnt = p.read_smem_cnt[r];
+  const uint64_t c0 = p.read_cand_off[r], nh = p.read_cand_off[r + 1] - c0;
+  rec.cand_off = c0;
+  rec.n_hits = nh > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nh;
+  rec.qpos0 = rec.len0 = 0;
+  rec.lo0 = rec.hi0 = rec.sa0 = 0;
+  if (rec.smem_cnt > 0 && *p.fault_seed == 0) {  // after a pool overflow the runs are incomplete (the batch is replayed)
+    const SmemT<C> sm = p.smems[rec.smem_off];
+    rec.qpos0 = sm.qpos;
+    rec.len0 = sm.len;
+    rec.lo0 = sm.lo;
+    rec.hi0 = sm.hi;
+    if (sm.hi > sm.lo) rec.sa0 = p.sa[sm.hi - 1];
+  }
+  p.recs[r] = rec;
 }
 
 // Mem list of Index::all_smems for thm_smems_batch: one wave per read
@@ -916,6 +891,11 @@ static hipError_t launch_seed_t(const SeedParamsT<C>& p, int n_blocks, hipStream
 hipError_t launch_seed(const SeedParamsT<uint32_t>& p, int n_blocks, hipStream_t s) { return launch_seed_t(p, n_blocks, s); }
 hipError_t launch_seed(const SeedParamsT<uint64_t>& p, int n_blocks, hipStream_t s) { return launch_seed_t(p, n_blocks, s); }
 
+hipError_t launch_plan(const PlanParams& p, hipStream_t s) {
+  if (p.n_reads == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::plan_kernel, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
 
 template <class C>
 static hipError_t launch_pack_reads_t(const PackParamsT<C>& p, hipStream_t s) {

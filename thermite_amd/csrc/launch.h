@@ -69,7 +69,7 @@ struct SeedParamsT {
   unsigned long long* work_short;   // [n_reads] short reads that need more than the probe at position 0
   unsigned long long* work_long;    // [n_long] long reads, the same
   unsigned long long* work_cells;   // [cells] (read << 16 | cell) of grid cells to probe
-  unsigned long long* work_counts;  // [16] list lengths: 0 short, 1 cells, 2 heavy, 3 select overflow, 4 long, 5 slow, 6 contract, 7 team, 8 / 9 schedule positions; zeroed before launch
+  unsigned long long* work_counts;  // [8] list lengths: 0 short, 1 cells, 2 heavy, 3 select overflow, 4 long, 5 slow; zeroed before launch
   SmemT<C>* smems;             // pool
   uint64_t smem_cap;           // pool capacity (entries)
   unsigned long long* cursor;  // bump allocator head (entries), zeroed before launch
@@ -90,9 +90,8 @@ hipError_t launch_seed(const SeedParamsT<uint32_t>& p, int n_blocks, hipStream_t
 hipError_t launch_seed(const SeedParamsT<uint64_t>& p, int n_blocks, hipStream_t s);
 hipError_t launch_sanitize(const uint8_t* in, uint8_t* out, uint64_t n, uint64_t n_padded, hipStream_t s);
 
-// After the seed stage (part of pack_reads_kernel): list the reads of the fast class with >= HEAVY_HITS hits
-// (heavy[0 .. counts[2])), the reads of the slow class (slow[0 .. counts[5])), the team's reads, and give reads
-// beyond every class their status.  The lists hold positions in the record array (schedule order).
+// After the seed stage: list the reads of the fast class with >= HEAVY_HITS hits (heavy[0 .. counts[2])), the reads
+// of the slow class (slow[0 .. counts[5])), and give reads beyond every class their status.
 struct PlanParams {
   const uint64_t* offsets;
   const uint64_t* read_hits;
@@ -110,6 +109,7 @@ struct PlanParams {
   uint32_t* read_n_alns;       // zeroed for unsupported reads
   uint64_t* read_op_bytes;
 };
+hipError_t launch_plan(const PlanParams& p, hipStream_t s);
 
 // Everything the extend kernel needs to start on a read, in one 64-byte record (one scalar load instead of a chain of
 // dependent ones: offsets, SMEM run, candidate slice, first SMEM, its first suffix-array entry).  Written by
@@ -125,16 +125,8 @@ struct ReadRecT {
   uint16_t qpos0, len0;  // the first SMEM of the run ...
   C lo0, hi0;
   C sa0;               // ... and its first occurrence in align_read's order, sa[hi0 - 1]
-  uint32_t read_idx;   // the read this record describes: records are laid out in SCHEDULE order (below), not read order
 };
-static_assert(sizeof(ReadRecT<uint32_t>) == 56 && sizeof(ReadRecT<uint64_t>) == 72, "ReadRec layout");
-// Schedule order: the extend kernel hands out records front to back, so pack_reads_kernel puts the reads whose cost
-// is known to be small and uniform LAST -- no seed, or one seed that spans the whole read and occurs once (an
-// error-free read: no DP at all, ~15 us) -- and everything else first.  When the expensive reads (100 - 800 us is
-// common: several hits, full DP on both sides, many transcripts) run out, the waves that are still inside one finish
-// under cover of the cheap ones; in read order the launch ended 0.7 ms after the queue ran dry, whatever the batch
-// size (tools/timeline.py).  Positions come from two block-aggregated atomic counters, one growing from each end;
-// the heavy / team / slow / retry lists hold positions too.
+static_assert(sizeof(ReadRecT<uint32_t>) == 56 && sizeof(ReadRecT<uint64_t>) == 64, "ReadRec layout");
 template <class C>
 struct PackParamsT {
   const C* sa;
@@ -146,7 +138,6 @@ struct PackParamsT {
   const uint64_t* read_cand_off;  // [n_reads + 1]
   const int* fault_seed;
   ReadRecT<C>* recs;
-  PlanParams plan;                // classes and lists (plan.counts[8], [9]: the two position counters)
 };
 hipError_t launch_pack_reads(const PackParamsT<uint32_t>& p, hipStream_t s);
 hipError_t launch_pack_reads(const PackParamsT<uint64_t>& p, hipStream_t s);
@@ -190,14 +181,7 @@ struct Cand {
 // work counters of the extend kernel: EXT_NQ of them, EXT_QSTRIDE u32 apart (separate cache lines)
 constexpr unsigned EXT_NQ = 8, EXT_QSTRIDE = 64;
 constexpr size_t QUEUE_BYTES = (EXT_NQ + 3) * EXT_QSTRIDE * 4;  // + the counters of the heavy-read list, the slow list and the team list
-#ifndef THM_HEAVY_HITS
-#define THM_HEAVY_HITS 8
-#endif
-#ifndef THM_SCHED_LIGHT
-#define THM_SCHED_LIGHT 1
-#endif
-constexpr unsigned HEAVY_HITS = THM_HEAVY_HITS;  // reads with at least this many seed hits are scheduled first
-constexpr bool SCHED_LIGHT_LAST = THM_SCHED_LIGHT != 0;
+constexpr unsigned HEAVY_HITS = 8;  // reads with at least this many seed hits are scheduled first
 // Reads with very many hits are worked on by a whole workgroup (extend_kernel, TEAM): speculative chunks of hits.
 // Which reads: a wave takes ~20 us per hit (a chain of dependent memory round trips) whatever else runs, the whole
 // machine ~4.5 ns per hit of a batch (256 CUs) -- a read whose hits take one wave longer than the rest of the batch
@@ -208,11 +192,7 @@ constexpr bool SCHED_LIGHT_LAST = THM_SCHED_LIGHT != 0;
 constexpr unsigned TEAM_HITS = 256;
 constexpr unsigned TEAM_MIN_HITS = 32;
 constexpr unsigned TEAM_DIV_PER_CU = 22;
-#ifndef THM_TEAM_WAVES
-#define THM_TEAM_WAVES 16
-#endif
-constexpr int TEAM_WAVES = THM_TEAM_WAVES;
-constexpr int TEAM_BLOCKS_PER_CU = 16 / TEAM_WAVES;  // team workgroups launched per CU
+constexpr int TEAM_WAVES = 16;
 constexpr unsigned TEAM_MAX_HITS = 60000;   // beyond that the team's per-chunk book (16384 chunks of 4 hits, less one per SMEM) does not fit: sequential path
 // intron markers one alignment can carry in the register-resident kernel (LDS); an alignment across more
 // introns sends its read to the any-width kernel, whose marker list is sized by the longest transcript

@@ -101,8 +101,8 @@ int enqueue_seed_t(thm_aligner* a, uint32_t min_seed_len) {
   HIPCHK(a, a->s_work_reads.ensure((n + 1) * 8));
   HIPCHK(a, a->s_work_long.ensure((n_long + 1) * 8));
   HIPCHK(a, a->s_work_cells.ensure((std::max(cells, n) + 1) * 8));
-  HIPCHK(a, a->s_work_counts.ensure(128));
-  HIPCHK(a, hipMemsetAsync(a->s_work_counts.p, 0, 128, s));
+  HIPCHK(a, a->s_work_counts.ensure(64));
+  HIPCHK(a, hipMemsetAsync(a->s_work_counts.p, 0, 64, s));
   int rc = reset_queue(a);
   if (rc != THM_OK) return rc;
   HIPCHK(a, hipMemsetAsync(a->d_cursors.p, 0, 64, s));
@@ -186,27 +186,6 @@ ExtClasses classify(const thm_aligner* a, uint32_t mk_cap_slow) {
   return c;
 }
 
-// one record per read in schedule order (offsets, SMEM run, candidate slice, first SMEM and its first occurrence) and
-// the extend stage's lists (launch.h, PackParamsT)
-template <class C>
-int enqueue_pack_t(thm_aligner* a, const PlanParams& pp) {
-  const uint64_t n = a->n_reads;
-  HIPCHK(a, a->e_recs.ensure((n + 1) * sizeof(ReadRecT<C>)));
-  PackParamsT<C> pk;
-  pk.sa = dev_view<C>(a).sa;
-  pk.offsets = a->r_offsets.as<uint64_t>();
-  pk.n_reads = n;
-  pk.smems = a->s_smems.as<SmemT<C>>();
-  pk.read_smem_off = a->s_off.as<uint64_t>();
-  pk.read_smem_cnt = a->s_cnt.as<uint32_t>();
-  pk.read_cand_off = a->s_cand_off.as<uint64_t>();
-  pk.fault_seed = a->d_fault.as<int>();
-  pk.recs = a->e_recs.as<ReadRecT<C>>();
-  pk.plan = pp;
-  HIPCHK(a, launch_pack_reads(pk, a->stream));
-  return THM_OK;
-}
-
 template <class C>
 int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow, bool retry_possible) {
   const uint64_t n = a->n_reads;
@@ -218,12 +197,27 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   ep.reads.n_reads = n;
   ep.opts = a->opts;
   ep.smems = a->s_smems.as<SmemT<C>>();
-  ep.read_recs = a->e_recs.as<ReadRecT<C>>();  // enqueue_pack_t
+  // one record per read (offsets, SMEM run, candidate slice, first SMEM and its first occurrence)
+  HIPCHK(a, a->e_recs.ensure((n + 1) * sizeof(ReadRecT<C>)));
+  {
+    PackParamsT<C> pk;
+    pk.sa = ep.ix.sa;
+    pk.offsets = a->r_offsets.as<uint64_t>();
+    pk.n_reads = n;
+    pk.smems = ep.smems;
+    pk.read_smem_off = a->s_off.as<uint64_t>();
+    pk.read_smem_cnt = a->s_cnt.as<uint32_t>();
+    pk.read_cand_off = a->s_cand_off.as<uint64_t>();
+    pk.fault_seed = a->d_fault.as<int>();
+    pk.recs = a->e_recs.as<ReadRecT<C>>();
+    HIPCHK(a, launch_pack_reads(pk, s));
+  }
+  ep.read_recs = a->e_recs.as<ReadRecT<C>>();
   ep.heavy = a->s_heavy.as<unsigned long long>();
   ep.heavy_count = a->s_work_counts.as<unsigned long long>() + 2;
   ep.team = a->s_team.as<unsigned long long>();
   ep.team_count = a->s_work_counts.as<unsigned long long>() + 7;
-  ep.team_limit = 2u * (uint32_t)a->n_cu * TEAM_BLOCKS_PER_CU;
+  ep.team_limit = 2u * (uint32_t)a->n_cu;
   ep.cands = a->e_cands.as<Cand>();
   ep.cand_cap = a->cand_cap;
   ep.order = a->e_order.as<uint32_t>();
@@ -253,7 +247,7 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   const size_t lds = extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl);
   const int ext_blocks = blocks_for(a, n, lds);
   const bool team_ok = cpl <= 2 && lds / 4 * TEAM_WAVES <= EXTEND_LDS_LIMIT;
-  const size_t trace_waves = std::max<size_t>((size_t)ext_blocks * 4, team_ok ? (size_t)a->n_cu * TEAM_BLOCKS_PER_CU * TEAM_WAVES : 0);
+  const size_t trace_waves = std::max<size_t>((size_t)ext_blocks * 4, team_ok ? (size_t)a->n_cu * TEAM_WAVES : 0);
   HIPCHK(a, a->e_trace.ensure(trace_waves * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
   ep.trace_scratch = a->e_trace.as<unsigned long long>();
   // reads with very many hits: a workgroup per read (speculative chunks of hits, kernels_extend.hip TEAM) BESIDE the
@@ -266,7 +260,7 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     ExtendParamsT<C> tp = ep;
     tp.list_only = 1;
     HIPCHK(a, hipEventRecord(a->ev_fork, s));
-    HIPCHK(a, launch_extend(tp, cpl, a->n_cu * TEAM_BLOCKS_PER_CU, s, true));
+    HIPCHK(a, launch_extend(tp, cpl, a->n_cu, s, true));
     HIPCHK(a, hipStreamWaitEvent(a->stream2, a->ev_fork, 0));
     HIPCHK(a, launch_extend(ep, cpl, ext_blocks, a->stream2));
     HIPCHK(a, hipEventRecord(a->ev_join, a->stream2));
@@ -361,8 +355,7 @@ int enqueue_run(thm_aligner* a) {
   pp.read_status = a->r_status.as<int32_t>();
   pp.read_n_alns = a->e_nalns.as<uint32_t>();
   pp.read_op_bytes = a->e_opbytes.as<uint64_t>();
-  rc = a->dix->wide ? enqueue_pack_t<uint64_t>(a, pp) : enqueue_pack_t<uint32_t>(a, pp);
-  if (rc != THM_OK) return rc;
+  HIPCHK(a, launch_plan(pp, s));
   HIPCHK(a, hipEventRecord(a->ev[2], s));
 
   rc = a->dix->wide ? enqueue_extend_t<uint64_t>(a, cls, mk_cap_slow, retry_possible)

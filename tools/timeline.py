@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""When do the waves of the wave-per-read extend kernel run out of work?  Needs a library built with -DTHM_TIMELINE
-(THM_LIB=...).   python tools/timeline.py [n_reads] [stream]"""
+"""When do the waves of the wave-per-read extend kernel run out of work?  Needs the diagnosis build: make -C thermite_amd/csrc timeline;
+THM_LIB=thermite_amd/_build/libthermite_amd_timeline.so   python tools/timeline.py [n_reads] [stream]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
