@@ -110,7 +110,7 @@ struct thm_aligner {
       s_work_counts, s_sel_scratch, s_heavy, s_slow, s_team;
   uint64_t smem_cap = 0;
   // extension
-  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace, e_slow, e_recs;
+  DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace, e_slow, e_recs, e_wcnt;
   uint64_t n_slow_host = 0;     // reads of the slow class in the last enqueue (host count)
   uint32_t fast_max_len = 0, slow_max_len = 0;
   uint64_t cand_cap = 0, cand_ops_cap = 0;

@@ -1744,19 +1744,36 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
   if (lane == 0) {
     if (batch_fault) atomicOr(p.fault, batch_fault & (FAULT_OPS_POOL | FAULT_INTERNAL));
     if (k_reads | k_calls | k_cells | k_win) {
-      atomicAdd(&p.counters[THM_CNT_READS], k_reads);
-      atomicAdd(&p.counters[THM_CNT_ALIGNED], k_aligned);
-      atomicAdd(&p.counters[THM_CNT_UNMAPPED], k_unmapped);
-      atomicAdd(&p.counters[THM_CNT_ALNS], k_alns);
-      atomicAdd(&p.counters[THM_CNT_EXONIC], (unsigned long long)k_type[0]);
-      atomicAdd(&p.counters[THM_CNT_INTRONIC], (unsigned long long)k_type[1]);
-      atomicAdd(&p.counters[THM_CNT_INTERGENIC], (unsigned long long)k_type[2]);
-      atomicAdd(&p.counters[THM_CNT_SWG_CALLS], k_calls);
-      atomicAdd(&p.counters[THM_CNT_DP_CELLS], k_cells);
-      atomicAdd(&p.counters[THM_CNT_DP_COLS], k_cols);
-      atomicAdd(&p.counters[THM_CNT_OP_BYTES], k_opb);
-      atomicAdd(&p.counters[THM_CNT_WINDOW_BYTES], k_win);
+      unsigned long long* row = p.wave_counters + (size_t)wave_global * THM_N_COUNTERS;
+      row[THM_CNT_READS] = k_reads;
+      row[THM_CNT_ALIGNED] = k_aligned;
+      row[THM_CNT_UNMAPPED] = k_unmapped;
+      row[THM_CNT_ALNS] = k_alns;
+      row[THM_CNT_EXONIC] = (unsigned long long)k_type[0];
+      row[THM_CNT_INTRONIC] = (unsigned long long)k_type[1];
+      row[THM_CNT_INTERGENIC] = (unsigned long long)k_type[2];
+      row[THM_CNT_SWG_CALLS] = k_calls;
+      row[THM_CNT_DP_CELLS] = k_cells;
+      row[THM_CNT_DP_COLS] = k_cols;
+      row[THM_CNT_OP_BYTES] = k_opb;
+      row[THM_CNT_WINDOW_BYTES] = k_win;
     }
+  }
+}
+
+// counters[k] += sum of wave_counters[row][k] (the rows the extend kernels' waves left; zeroed before the launches)
+__global__ __launch_bounds__(1024) void counters_reduce_kernel(const unsigned long long* rows, uint32_t n_rows, unsigned long long* counters) {
+  __shared__ unsigned long long part[64][THM_N_COUNTERS];
+  static_assert(THM_N_COUNTERS == 16, "one thread per counter and row group");
+  const int k = (int)(threadIdx.x & 15u), g = (int)(threadIdx.x >> 4);
+  unsigned long long sum = 0;
+  for (uint32_t r = (uint32_t)g; r < n_rows; r += 64) sum += rows[(size_t)r * THM_N_COUNTERS + k];
+  part[g][k] = sum;
+  __syncthreads();
+  if (g == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 64; i++) t += part[i][k];
+    if (t) counters[k] += t;
   }
 }
 
@@ -1914,6 +1931,12 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
 }
 hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s, bool team) { return launch_extend_t(p, cpl, n_blocks, s, team); }
 hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s, bool team) { return launch_extend_t(p, cpl, n_blocks, s, team); }
+
+hipError_t launch_counters_reduce(const unsigned long long* wave_counters, uint32_t n_rows, unsigned long long* counters, hipStream_t s) {
+  if (n_rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(dev::counters_reduce_kernel, dim3(1), dim3(1024), 0, s, wave_counters, n_rows, counters);
+  return hipGetLastError();
+}
 
 hipError_t launch_compact(const CompactParams& p, hipStream_t s) {
   const unsigned blocks = (unsigned)((p.n_reads + 15) / 16);

@@ -256,9 +256,24 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   // waves of the main kernel fill the machine: the team kernel goes first on this stream, the main kernel on the second
   // stream behind an event (the event's latency is the team's head start; the other way round the team kernel started
   // 10 us late and waited for the main kernel to drain -- rocprofv3 kernel trace, tools/overlap_trace.py).
+  // rows for the waves' counters: [main | team | slow] (launch.h, ExtendParamsT::wave_counters)
+  uint64_t slow_waves = 0, slow_per_wave = 0;
+  if (cls.n_slow || retry_possible) {
+    const uint32_t sl_len = std::max(cls.slow_len, cls.fast_len), sl_bw = std::max(cls.slow_bw, cls.fast_bw);
+    slow_per_wave = (extend_slow_scratch_bytes(sl_len, sl_bw, mk_cap_slow) + 255) & ~255ull;
+    slow_waves = std::max<uint64_t>(1, std::min<uint64_t>(SLOW_SCRATCH_BUDGET / std::max<uint64_t>(slow_per_wave, 1), (uint64_t)a->n_cu * 8));
+    if (!retry_possible) slow_waves = std::min(slow_waves, std::max<uint64_t>(cls.n_slow, 1));
+    slow_waves = (slow_waves + 3) / 4 * 4;
+  }
+  const uint64_t main_rows = (uint64_t)ext_blocks * 4, team_rows = team_ok ? (uint64_t)a->n_cu * TEAM_WAVES : 0;
+  const uint64_t n_rows = main_rows + team_rows + slow_waves;
+  HIPCHK(a, a->e_wcnt.ensure(n_rows * THM_N_COUNTERS * 8 + 64));
+  HIPCHK(a, hipMemsetAsync(a->e_wcnt.p, 0, n_rows * THM_N_COUNTERS * 8, s));
+  ep.wave_counters = a->e_wcnt.as<unsigned long long>();
   if (team_ok) {
     ExtendParamsT<C> tp = ep;
     tp.list_only = 1;
+    tp.wave_counters = ep.wave_counters + main_rows * THM_N_COUNTERS;
     HIPCHK(a, hipEventRecord(a->ev_fork, s));
     HIPCHK(a, launch_extend(tp, cpl, a->n_cu, s, true));
     HIPCHK(a, hipStreamWaitEvent(a->stream2, a->ev_fork, 0));
@@ -271,10 +286,9 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   // ---- slow class (and the fast kernel's retries) ----
   if (cls.n_slow || retry_possible) {
     const uint32_t sl_len = std::max(cls.slow_len, cls.fast_len), sl_bw = std::max(cls.slow_bw, cls.fast_bw);
-    const uint64_t per_wave = (extend_slow_scratch_bytes(sl_len, sl_bw, mk_cap_slow) + 255) & ~255ull;
-    uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(SLOW_SCRATCH_BUDGET / std::max<uint64_t>(per_wave, 1), (uint64_t)a->n_cu * 8));
-    if (!retry_possible) waves = std::min(waves, std::max<uint64_t>(cls.n_slow, 1));
-    const int blocks = (int)((waves + 3) / 4);
+    const uint64_t per_wave = slow_per_wave;
+    const int blocks = (int)(slow_waves / 4);
+    ep.wave_counters = a->e_wcnt.as<unsigned long long>() + (main_rows + team_rows) * THM_N_COUNTERS;
     HIPCHK(a, a->e_slow.ensure((size_t)blocks * 4 * per_wave + 256));
     ep.max_read_len = sl_len;
     ep.max_bw = sl_bw;
@@ -288,6 +302,7 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     ep.slow_scratch_per_wave = per_wave;
     HIPCHK(a, launch_extend(ep, 0, blocks, s));
   }
+  HIPCHK(a, launch_counters_reduce(a->e_wcnt.as<unsigned long long>(), (uint32_t)n_rows, a->d_counters.as<unsigned long long>(), s));
   return THM_OK;
 }
 
