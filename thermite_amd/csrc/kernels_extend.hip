@@ -1871,6 +1871,24 @@ size_t extend_slow_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, uint32_
   return (size_t)dev::slow_layout(max_read_len, max_bw, mk_cap).total;
 }
 
+// waves per SIMD the wave-per-read kernel chosen for (cpl, coordinate width) is compiled for = workgroups of 4 waves
+// that fit a CU; the host launches no more than that (a workgroup beyond it starts when the first ones leave, finds
+// the work counters dry and only delays the end of the launch)
+int extend_waves_per_simd(int cpl, bool wide) {
+  static const int minw_env = [] {
+    const char* e = getenv("THM_EXT_MINW");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 4 && v <= 8) ? v : 0;
+  }();
+  if (cpl == 0) return 2;
+  if (wide || cpl > 2) return 4;
+  if (minw_env) {
+    if (cpl == 1) return (minw_env == 4 || minw_env == 5 || minw_env == 6) ? minw_env : 8;
+    return (minw_env == 4 || minw_env == 5 || minw_env == 8) ? minw_env : 6;
+  }
+  return cpl == 1 ? 6 : 5;
+}
+
 template <class C>
 static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_blocks, hipStream_t s, bool team) {
   const size_t lds4 = cpl == 0 ? 0 : extend_lds_bytes(p.max_read_len, p.max_bw, cpl);
@@ -1896,11 +1914,6 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
   // system (rocprofv3 FETCH_SIZE / WRITE_SIZE) against 1.2 GB at 5 and 0.53 GB of algorithmic bytes: 1 % of throughput
   // for 2.6x less traffic -> 5.  Wider bands run at 4.  Tuning knob THM_EXT_MINW = 4 | 5 | 6 | 8 for the one- and
   // two-cell kernels.  The 64-bit-coordinate kernels carry more live state per hit and run at 4 waves per SIMD.
-  static const int minw_env = [] {
-    const char* e = getenv("THM_EXT_MINW");
-    const int v = e ? atoi(e) : 0;
-    return (v >= 4 && v <= 8) ? v : 0;
-  }();
   if (cpl == 0) return go(dev::extend_kernel<C, 0, 2>);
   if constexpr (sizeof(C) == 8) {
     switch (cpl) {
@@ -1911,7 +1924,7 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
       default: return hipErrorInvalidValue;
     }
   } else {
-    const int minw = minw_env ? minw_env : (cpl == 1 ? 6 : cpl == 2 ? 5 : 4);
+    const int minw = extend_waves_per_simd(cpl, false);
     switch (cpl) {
       case 1:
         if (minw == 4) return go(dev::extend_kernel<C, 1, 4>);

@@ -243,6 +243,7 @@ struct ExtendParamsT {
   unsigned long long* prof;  // 16 slots of shader clocks per section (THM_PROF builds), else unused
 };
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
+int extend_waves_per_simd(int cpl, bool wide);
 size_t extend_trace_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
 size_t extend_slow_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, uint32_t mk_cap);  // per wave
 constexpr size_t EXTEND_LDS_LIMIT = 160 * 1024;  // gfx950: one workgroup may take the whole LDS of its CU

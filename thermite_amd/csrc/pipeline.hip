@@ -245,7 +245,8 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   ep.list_only = 0;
   const int cpl = std::max(1, (int)((2 * cls.fast_bw + 1 + 63) / 64));
   const size_t lds = extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl);
-  const int ext_blocks = blocks_for(a, n, lds);
+  // workgroups that fit the machine at once: LDS and the kernel's register budget
+  const int ext_blocks = std::min(blocks_for(a, n, lds), a->n_cu * extend_waves_per_simd(cpl, sizeof(C) == 8));
   const bool team_ok = cpl <= 2 && lds / 4 * TEAM_WAVES <= EXTEND_LDS_LIMIT;
   const size_t trace_waves = std::max<size_t>((size_t)ext_blocks * 4, team_ok ? (size_t)a->n_cu * TEAM_WAVES : 0);
   HIPCHK(a, a->e_trace.ensure(trace_waves * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
