@@ -287,7 +287,8 @@ def main():
             a = aligners[t]
             for j in range(per_thread):
                 bases, offsets = batches[(t + n_thr * j) % NB]
-                a.align_batch(bases, offsets)  # H2D of the reads, kernels, D2H of alignments + op streams
+                a.align_batch(bases, offsets, copy=False)  # H2D of the reads, kernels, D2H of alignments + op streams into the
+                # aligner's pinned result set; the views are what a C caller gets (no further copy into numpy arrays)
 
         barrier()
         t1 = time.perf_counter()

@@ -379,3 +379,16 @@ def test_heavy_reads_thousands_of_hits(heavy):
     check_align(heavy, b2, o2, capi.CI_OPTS)
     check_align(heavy, b2, o2, capi.DEFAULT_OPTS)
     check_align(heavy, b2, o2, dict(capi.CI_OPTS, multimap_score_range=6, min_seed_len=16))
+
+
+def test_result_views_without_copy(chrm):
+    """thm_batch_view points into the aligner's pinned result sets (two, used alternately): the binding can hand out
+    numpy views of them instead of copies; a view stays valid over the next fetch and is reused by the one after."""
+    bases, off, _ = synth.simulate_reads(chrm.t, 3000, 91, sub_rate=0.01, indel_rate=0.001, stream=7)
+    b2, o2, _ = synth.simulate_reads(chrm.t, 2000, 91, sub_rate=0.02, stream=8)
+    a = chrm.aligner(capi.CI_OPTS)
+    want = a.align_batch(bases, off)
+    v = a.align_batch(bases, off, copy=False)
+    assert not v.alns.flags.owndata and np.array_equal(v.alns, want.alns) and np.array_equal(v.ops, want.ops)
+    a.align_batch(b2, o2, copy=False)  # the other result set: v is untouched
+    assert np.array_equal(v.alns, want.alns) and np.array_equal(v.ops, want.ops) and np.array_equal(v.offsets, want.offsets)

@@ -244,12 +244,13 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def _copy(ptr, count, dtype):
+def _copy(ptr, count, dtype, copy=True):
     if count == 0 or not ptr:
         return np.zeros(0, dtype=dtype)
     nbytes = int(count) * np.dtype(dtype).itemsize
     buf = (C.c_uint8 * nbytes).from_address(ptr)
-    return np.frombuffer(buf, dtype=dtype, count=int(count)).copy()
+    a = np.frombuffer(buf, dtype=dtype, count=int(count))
+    return a.copy() if copy else a
 
 
 def _u8(b):
@@ -419,16 +420,18 @@ class Index:
 
 
 class BatchResult:
-    """Canonical host result of one aligned batch (thm_batch_view copied out)."""
+    """Canonical host result of one aligned batch: thm_batch_view copied out, or (copy=False) numpy views of the
+    aligner's pinned result set itself -- what a C caller gets; valid until the second fetch after this one
+    (include/thermite.h, thm_batch_view)."""
 
-    def __init__(self, view):
+    def __init__(self, view, copy=True):
         self.n_reads = view.n_reads
-        self.offsets = _copy(view.read_aln_off, view.n_reads + 1, "<u8")
-        self.alns = _copy(view.alns, view.n_alns, ALN_DT)
-        self.ops = _copy(view.ops, view.n_op_bytes, np.uint8)
+        self.offsets = _copy(view.read_aln_off, view.n_reads + 1, "<u8", copy)
+        self.alns = _copy(view.alns, view.n_alns, ALN_DT, copy)
+        self.ops = _copy(view.ops, view.n_op_bytes, np.uint8, copy)
         self.n_failed = view.n_failed_reads
         # per-read status (0 = ok); None when every read is ok
-        self.status = _copy(view.read_status, view.n_reads, "<i4") if view.read_status else None
+        self.status = _copy(view.read_status, view.n_reads, "<i4", copy) if view.read_status else None
 
 
 class Aligner:
@@ -465,11 +468,11 @@ class Aligner:
     def stream(self):
         return lib().thm_aligner_stream(self.h)
 
-    def align_batch(self, bases, offsets):
+    def align_batch(self, bases, offsets, copy=True):
         bases, offsets = _u8(bases), np.ascontiguousarray(offsets, "<u8")
         v = BatchView()
         self._chk(lib().thm_align_batch(self.h, _ptr(bases), _ptr(offsets), len(offsets) - 1, C.byref(v)))
-        return BatchResult(v)
+        return BatchResult(v, copy)
 
     def upload(self, bases, offsets):
         bases, offsets = _u8(bases), np.ascontiguousarray(offsets, "<u8")
@@ -481,10 +484,10 @@ class Aligner:
     def sync(self):
         self._chk(lib().thm_batch_sync(self.h))
 
-    def fetch(self):
+    def fetch(self, copy=True):
         v = BatchView()
         self._chk(lib().thm_batch_fetch(self.h, C.byref(v)))
-        return BatchResult(v)
+        return BatchResult(v, copy)
 
     def smems_batch(self, bases, offsets, min_seed_len):
         bases, offsets = _u8(bases), np.ascontiguousarray(offsets, "<u8")
