@@ -392,3 +392,13 @@ def test_result_views_without_copy(chrm):
     assert not v.alns.flags.owndata and np.array_equal(v.alns, want.alns) and np.array_equal(v.ops, want.ops)
     a.align_batch(b2, o2, copy=False)  # the other result set: v is untouched
     assert np.array_equal(v.alns, want.alns) and np.array_equal(v.ops, want.ops) and np.array_equal(v.offsets, want.offsets)
+
+
+def test_every_read_length_class_launches(syn):
+    """Buffers (and with them the LDS of the 16-wave team workgroup, which carries 17 KB of its own) grow with the read
+    length: every length up to the end of the two-cells-per-lane class must find a launchable configuration.  (A length
+    whose team workgroup passed the size check without its static part failed the whole batch: found by tools/fuzz_gpu.py.)"""
+    opts = dict(capi.DEFAULT_OPTS, min_aln_score_percent=0.8)
+    for L in range(96, 316, 12):
+        bases, off, _ = synth.simulate_reads(syn.t, 120, L, sub_rate=0.01, indel_rate=0.001, stream=300 + L)
+        check_align(syn, bases, off, opts)

@@ -648,6 +648,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
   __shared__ int t_state[4];          // the state in force at chunk t_ctl[1]: band, X-drop, best score
   __shared__ unsigned t_ctl[4];       // [0] list slot of the read, [1] first chunk of the round, [2] accepted so far, [3] per-read fault bits
   __shared__ unsigned char t_nacc[TM ? TEAM_MAX_CHUNKS : 1];  // accepted candidates per finished chunk (<= TEAM_CHUNK)
+  static_assert(!TM || sizeof(t_res) + sizeof(t_state) + sizeof(t_ctl) + sizeof(t_nacc) <= TEAM_STATIC_LDS, "launch.h: TEAM_STATIC_LDS");
   typedef WctxT<GS> Wctx;
   // The parameter block (about 80 dwords) is read from the kernel-argument segment where it is
   // needed (scalar loads, THM_KARG_QUAL = volatile keeps them at their use sites) instead of being

@@ -247,6 +247,10 @@ int extend_waves_per_simd(int cpl, bool wide);
 size_t extend_trace_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl);
 size_t extend_slow_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, uint32_t mk_cap);  // per wave
 constexpr size_t EXTEND_LDS_LIMIT = 160 * 1024;  // gfx950: one workgroup may take the whole LDS of its CU
+// does a team workgroup (TEAM_WAVES waves' buffers + the team's own static LDS: per-chunk book, round results) fit?
+// lds4 = extend_lds_bytes(...) of an ordinary 4-wave workgroup
+constexpr size_t TEAM_STATIC_LDS = 16384 + TEAM_WAVES * 32 + 64;  // t_nacc[TEAM_MAX_CHUNKS], t_res, t_state, t_ctl (kernels_extend.hip)
+inline bool team_fits_lds(size_t lds4) { return lds4 / 4 * TEAM_WAVES + TEAM_STATIC_LDS + 256 <= EXTEND_LDS_LIMIT; }
 // team = true: the workgroup-per-read variant for reads with very many hits (cpl 1 or 2 only; TEAM_WAVES waves per workgroup)
 hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s, bool team = false);
 hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s, bool team = false);

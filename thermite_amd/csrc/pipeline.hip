@@ -247,7 +247,7 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   const size_t lds = extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl);
   // workgroups that fit the machine at once: LDS and the kernel's register budget
   const int ext_blocks = std::min(blocks_for(a, n, lds), a->n_cu * extend_waves_per_simd(cpl, sizeof(C) == 8));
-  const bool team_ok = cpl <= 2 && lds / 4 * TEAM_WAVES <= EXTEND_LDS_LIMIT;
+  const bool team_ok = cpl <= 2 && team_fits_lds(lds);
   const size_t trace_waves = std::max<size_t>((size_t)ext_blocks * 4, team_ok ? (size_t)a->n_cu * TEAM_WAVES : 0);
   HIPCHK(a, a->e_trace.ensure(trace_waves * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
   ep.trace_scratch = a->e_trace.as<unsigned long long>();
@@ -356,7 +356,7 @@ int enqueue_run(thm_aligner* a) {
   pp.team = a->s_team.as<unsigned long long>();
   {
     const int cpl_f = std::max(1, (int)((2 * cls.fast_bw + 1 + 63) / 64));
-    pp.team_ok = (cpl_f <= 2 && extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl_f) / 4 * TEAM_WAVES <= EXTEND_LDS_LIMIT) ? 1u : 0u;
+    pp.team_ok = (cpl_f <= 2 && team_fits_lds(extend_lds_bytes(cls.fast_len, cls.fast_bw, cpl_f))) ? 1u : 0u;
   }
   pp.total_hits = a->s_cand_off.as<uint64_t>() + n;
   {

@@ -19,8 +19,6 @@ for r in range(rounds):
     L = int(rng.choice([30, 50, 75, 91, 120, 150, 200, 260]))
     k = int(rng.integers(8, 26))
     pct = float(rng.choice([0.0, 0.3, 0.5, 0.66, 0.8, 0.9]))
-    if L - int(pct * L) > 127 or (L > 150 and pct < 0.66):
-        pct = 0.8  # keep the band within the build's limits
     opts = dict(min_seed_len=k, min_aln_score_percent=pct, min_aln_score=int(rng.choice([0, 20, 30])),
                 multimap_score_range=int(rng.integers(0, 4)), intron_mode=bool(rng.integers(0, 2)))
     n = int(rng.integers(500, 6000))
