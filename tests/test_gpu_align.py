@@ -381,6 +381,23 @@ def test_heavy_reads_thousands_of_hits(heavy):
     check_align(heavy, b2, o2, dict(capi.CI_OPTS, multimap_score_range=6, min_seed_len=16))
 
 
+@pytest.fixture(params=[False, True], ids=["c32", "c64"])
+def heavy_small(request):
+    return _world("heavy_small", lambda: synth.heavy_repeat_reference(length=1500000, copies=1200)[0], request.param)
+
+
+def test_team_and_main_kernel_side_by_side_with_global_traces(heavy_small):
+    """120-base reads, band +-41 (two cells per lane): extensions of 64 bases and more keep their trace in the wave's
+    slice of global scratch, in the team kernel and in the wave-per-read kernel, which run at the same time.  (They
+    indexed one scratch array by wave number: a team wave and a main wave overwrote each other's traces -- same
+    scores and coordinates, a different CIGAR.  Found by tools/fuzz_gpu.py 12 12 heavy.)"""
+    w = heavy_small
+    opts = dict(min_seed_len=15, min_aln_score_percent=0.66, min_aln_score=20, multimap_score_range=2, intron_mode=True)
+    for rep in range(3):  # a race: more than one chance to show
+        bases, off, _ = synth.simulate_reads(w.t, 5000, 120, sub_rate=0.03, indel_rate=0.01, intronic_frac=0.2, stream=1001 + rep)
+        check_align(w, bases, off, opts)
+
+
 def test_result_views_without_copy(chrm):
     """thm_batch_view points into the aligner's pinned result sets (two, used alternately): the binding can hand out
     numpy views of them instead of copies; a view stays valid over the next fetch and is reused by the one after."""

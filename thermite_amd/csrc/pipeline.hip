@@ -248,8 +248,11 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   // workgroups that fit the machine at once: LDS and the kernel's register budget
   const int ext_blocks = std::min(blocks_for(a, n, lds), a->n_cu * extend_waves_per_simd(cpl, sizeof(C) == 8));
   const bool team_ok = cpl <= 2 && team_fits_lds(lds);
-  const size_t trace_waves = std::max<size_t>((size_t)ext_blocks * 4, team_ok ? (size_t)a->n_cu * TEAM_WAVES : 0);
-  HIPCHK(a, a->e_trace.ensure(trace_waves * extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl) + 64));
+  // global trace scratch (extensions over more than 64 band slots): the team kernel runs BESIDE the main kernel, so
+  // its waves have their own slices behind the main kernel's
+  const size_t trace_per_wave = extend_trace_scratch_bytes(cls.fast_len, cls.fast_bw, cpl);
+  const size_t main_trace_waves = (size_t)ext_blocks * 4, team_trace_waves = team_ok ? (size_t)a->n_cu * TEAM_WAVES : 0;
+  HIPCHK(a, a->e_trace.ensure((main_trace_waves + team_trace_waves) * trace_per_wave + 64));
   ep.trace_scratch = a->e_trace.as<unsigned long long>();
   // reads with very many hits: a workgroup per read (speculative chunks of hits, kernels_extend.hip TEAM) BESIDE the
   // wave-per-read kernel: such reads are the long jobs of a batch, a launch behind the main kernel would put them on
@@ -275,6 +278,7 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     ExtendParamsT<C> tp = ep;
     tp.list_only = 1;
     tp.wave_counters = ep.wave_counters + main_rows * THM_N_COUNTERS;
+    tp.trace_scratch = ep.trace_scratch + main_trace_waves * trace_per_wave / 8;
     HIPCHK(a, hipEventRecord(a->ev_fork, s));
     HIPCHK(a, launch_extend(tp, cpl, a->n_cu, s, true));
     HIPCHK(a, hipStreamWaitEvent(a->stream2, a->ev_fork, 0));
