@@ -43,6 +43,8 @@ for r in range(rounds):
                 reads.insert(int(rng.integers(0, len(reads) + 1)), lb[lo[i]: lo[i + 1]])
     b2, o2 = refdata.pack_reads(reads)
     a = capi.Aligner(ix, opts)
+    if rng.random() < 0.25:  # small pools: overflow -> grow -> replay (thm_batch_sync)
+        a.debug_set_pool_caps(smem_cap=int(rng.integers(64, 2000)), cand_cap=int(rng.integers(16, 2000)), ops_cap=int(rng.integers(4096, 100000)))
     g = a.align_batch(b2, o2)
     ref = oix.align_batch(b2, o2, opts, n_threads=16)
     assert ref.counters[15] == 0
