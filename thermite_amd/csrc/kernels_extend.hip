@@ -1882,7 +1882,15 @@ int extend_waves_per_simd(int cpl, bool wide) {
     return (v >= 4 && v <= 8) ? v : 0;
   }();
   if (cpl == 0) return 2;
-  if (wide || cpl > 2) return 4;
+  if (cpl > 2) return 4;
+  if (wide) {
+    static const int wide_env = [] {
+      const char* e = getenv("THM_EXT_MINW_WIDE");
+      const int v = e ? atoi(e) : 0;
+      return (v == 4 || v == 5) ? v : 0;
+    }();
+    return wide_env ? wide_env : 5;
+  }
   if (minw_env) {
     if (cpl == 1) return (minw_env == 4 || minw_env == 5 || minw_env == 6) ? minw_env : 8;
     return (minw_env == 4 || minw_env == 5 || minw_env == 8) ? minw_env : 6;
@@ -1914,12 +1922,14 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
   // 4.30 at 7, 4.23 at 8, 4.64 at 4; but at 6 waves the spills move 3.2 GB per 500 k-read launch through the memory
   // system (rocprofv3 FETCH_SIZE / WRITE_SIZE) against 1.2 GB at 5 and 0.53 GB of algorithmic bytes: 1 % of throughput
   // for 2.6x less traffic -> 5.  Wider bands run at 4.  Tuning knob THM_EXT_MINW = 4 | 5 | 6 | 8 for the one- and
-  // two-cell kernels.  The 64-bit-coordinate kernels carry more live state per hit and run at 4 waves per SIMD.
+  // two-cell kernels.  The 64-bit-coordinate kernels (more live state per hit) were at 4 waves per SIMD until the end of
+  // round 2: 5 is 8 % faster (4.29 -> 3.95 ms on the benchmark workload with THM_FORCE_WIDE; knob THM_EXT_MINW_WIDE = 4 | 5).
   if (cpl == 0) return go(dev::extend_kernel<C, 0, 2>);
   if constexpr (sizeof(C) == 8) {
+    const int minw = extend_waves_per_simd(cpl, true);
     switch (cpl) {
-      case 1: return go(dev::extend_kernel<C, 1, 4>);
-      case 2: return go(dev::extend_kernel<C, 2, 4>);
+      case 1: return minw == 5 ? go(dev::extend_kernel<C, 1, 5>) : go(dev::extend_kernel<C, 1, 4>);
+      case 2: return minw == 5 ? go(dev::extend_kernel<C, 2, 5>) : go(dev::extend_kernel<C, 2, 4>);
       case 3: return go(dev::extend_kernel<C, 3, 4>);
       case 4: return go(dev::extend_kernel<C, 4, 4>);
       default: return hipErrorInvalidValue;
