@@ -764,7 +764,9 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
   const unsigned list_q = (GS ? EXT_NQ + 1 : EXT_NQ) * EXT_QSTRIDE;
   // (Issuing the atomic for the next read while the current one is worked on was tried: the pending return value
   // stays live across the whole hit loop and costs 400 bytes per lane of spills -- three times slower.)
-  unsigned pend_idx = 0, pend_n = 0;  // rest of the run of READ_RUN consecutive reads one queue atomic handed out
+  unsigned pend_idx = 0, pend_n = 0;  // rest of the run of consecutive reads one queue atomic handed out
+  // run length: at most READ_RUN, and short enough that every wave of the grid gets about eight runs (small batches)
+  const unsigned read_run = max(1u, min((unsigned)READ_RUN, n_total / (gridDim.x * 4u * 8u)));
   for (;;) {
     bool from_heavy = false, got = false;
     unsigned idx = 0;
@@ -799,13 +801,13 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
     }
     while (!got && q_tried < EXT_NQ && n_total) {
       unsigned g = 0;
-      if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, (unsigned)READ_RUN);
+      if (lane == 0) g = atomicAdd(p.queue + my_q * EXT_QSTRIDE, read_run);
       g = (unsigned)bcast_first((int)g);
       const unsigned lo = my_q * q_share, hi = min(lo + q_share, n_total);
       if (lo < hi && g < hi - lo) {
         idx = lo + g;
         pend_idx = idx + 1;
-        pend_n = min((unsigned)READ_RUN - 1u, hi - lo - g - 1u);
+        pend_n = min(read_run - 1u, hi - lo - g - 1u);
         got = true;
         break;
       }
