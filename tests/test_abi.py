@@ -54,3 +54,13 @@ def test_c_headers_are_plain_c(tmp_path):
     src.write_text('#include "thermite_io.h"\nint main(void) { thm_run_stats s; thm_aln a; (void)s; (void)a; return THM_OK; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
                            "-fsyntax-only", str(src)])
+
+
+def test_tools_and_bench_compile():
+    """the scripts under tools/ run only on the GPU box: at least keep them syntactically alive here"""
+    import glob
+    import py_compile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
+        py_compile.compile(f, doraise=True)
