@@ -289,13 +289,27 @@ def test_fastq_block_parser_equals_sequential_parser(data_dir, tmp_path, per_blo
             b = capi.FastqReader(p).all_by_blocks(per_block)
             got = _collect_one(b)
             assert got == want, (name, gz)
-    # malformed records are errors in the block parser too
-    for bad in (b"@r\nACGT\n+\n!!\n", b"@r\nACGT\nACGT\n!!!!\n", b"@r\nACGT\n", b"@a\nAC\n+\n!!\n\n@b\nAC\n+\n!!\n"):
+    # malformed records are errors in the block parser too -- also when the sequence line is most of the block (the
+    # parser copies a sequence before it has seen the record's '+' and quality lines: round-2 advisor finding, a heap
+    # overflow for sequences beyond half the block) -- and in the sequential parser, which accepts the same files
+    big = b"A" * 4000000
+    for bad in (b"@r\nACGT\n+\n!!\n", b"@r\nACGT\nACGT\n!!!!\n", b"@r\nACGT\n", b"@a\nAC\n+\n!!\n\n@b\nAC\n+\n!!\n",
+                b"@r0\n" + big + b"\n+\nII\n",            # quality much shorter than a long sequence
+                b"@r0\nAC\n+\nII\n@r1\n" + big + b"\n",  # truncated last record of a long read
+                b"@r0\n" + big + b"\n" + big + b"\n",       # no '+' after a long line
+                b"@r0\n" + b"A" * 9000 + b"\n+\n" + b"I" * 8999 + b"\n"):
         q = tmp_path / "bad.fastq"
         q.write_bytes(bad)
         with pytest.raises(capi.ThermiteError) as e:
             capi.FastqReader(q).all_by_blocks(per_block)
         assert e.value.code == capi.ERR_FORMAT
+        with pytest.raises(capi.ThermiteError) as e:
+            _collect(capi.FastqReader(q), 100)
+        assert e.value.code == capi.ERR_FORMAT
+    # a well-formed record of a long read is fine in both
+    q = tmp_path / "long.fastq"
+    q.write_bytes(b"@r0\n" + big + b"\n+\n" + b"I" * len(big) + b"\n@r1\nAC\n+\nII\n")
+    assert _collect_one(capi.FastqReader(q).all_by_blocks(per_block)) == _collect(capi.FastqReader(q), 100)
 
 
 def _collect_one(b):

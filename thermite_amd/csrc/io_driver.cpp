@@ -40,6 +40,7 @@ struct Slot {
   const char* raw_ptr = nullptr;  // ... or a range of the memory-mapped input file (plain input: no copy)
   size_t raw_len = 0;
   uint64_t first_line = 0;
+  bool last_block = false;  // nothing of this input file follows the block (blank lines are tolerated at its end)
   std::string path;
   bool parsed = false;  // `reads` already holds the batch (sequential parser: FASTA, odd inputs)
   thm::HostBatch reads;
@@ -82,6 +83,25 @@ struct Shared {
   bool failed() {
     std::lock_guard<std::mutex> g(mu);
     return rc != THM_OK;
+  }
+  // Runs one step of a pipeline thread.  An exception (bad_alloc from a growing buffer, mostly) must not leave the
+  // thread body: std::terminate would take the host process down, and a thread that simply stopped would leave the
+  // others waiting on its queue.  The step's failure becomes the run's status and the thread goes on with its
+  // hand-over protocol.
+  template <class F>
+  int step(F&& f) {
+    try {
+      return f();
+    } catch (const std::bad_alloc&) {
+      set(THM_ERR_OOM, "out of host memory in the file driver");
+      return THM_ERR_OOM;
+    } catch (const std::exception& e) {
+      set(THM_ERR_INTERNAL, std::string("file driver: ") + e.what());
+      return THM_ERR_INTERNAL;
+    } catch (...) {
+      set(THM_ERR_INTERNAL, "file driver: unknown exception");
+      return THM_ERR_INTERNAL;
+    }
   }
 };
 
@@ -225,15 +245,16 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
           if (p == map_len && p > p0 && map[p - 1] != '\n') n_lines++;
           s->raw_ptr = map + p0;
           s->raw_len = p - p0;
+          s->last_block = p == map_len;
           s->first_line = map_line;
           map_line += n_lines;
           map_pos = p;
           prc = THM_OK;
         } else if (fast) {
-          prc = thm::fastq_next_raw_block(r, batch_reads, s->raw, s->raw_len, n_lines, s->first_line);
+          prc = sh.step([&] { return thm::fastq_next_raw_block(r, batch_reads, s->raw, s->raw_len, n_lines, s->first_line, s->last_block); });
           s->raw_ptr = s->raw.data();
         } else {  // FASTA and anything that is not plain 4-line FASTQ: the sequential parser
-          prc = thm::fastq_fill(r, batch_reads, s->reads);
+          prc = sh.step([&] { return thm::fastq_fill(r, batch_reads, s->reads); });
           s->parsed = true;
           n_lines = s->reads.n_reads();
         }
@@ -273,7 +294,7 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
         if (!s->parsed && !sh.failed()) {
           const auto t0 = Clock::now();
           std::string err;
-          const int prc = thm::fastq_parse_block(s->raw_ptr, s->raw_len, s->path, s->first_line, s->reads, err);
+          const int prc = sh.step([&] { return thm::fastq_parse_block(s->raw_ptr, s->raw_len, s->path, s->first_line, s->last_block, s->reads, err); });
           {
             std::lock_guard<std::mutex> g(st_mu);
             st.parse_s += secs(t0, Clock::now());
@@ -314,12 +335,15 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
           next_align++;
         }
         par_cv.notify_all();
-        if (!sh.failed()) {
+        if (!sh.failed() && s->reads.n_reads() != 0) {  // (a blank tail cut into a block of its own holds no read)
           const auto t0 = Clock::now();
           const thm_read_batch rb = s->reads.view();
-          int grc = thm_batch_upload(a, rb.bases, rb.offsets, rb.n_reads);
-          if (grc == THM_OK) grc = thm_batch_run(a);
-          if (grc == THM_OK) grc = thm_batch_sync(a);
+          int grc = sh.step([&] {
+            int g2 = thm_batch_upload(a, rb.bases, rb.offsets, rb.n_reads);
+            if (g2 == THM_OK) g2 = thm_batch_run(a);
+            if (g2 == THM_OK) g2 = thm_batch_sync(a);
+            return g2;
+          });
           const auto t1 = Clock::now();
           // the fetch below reuses the buffers of this aligner's second-last fetch: that batch must have been written
           if (grc == THM_OK && fetched.size() >= 2) {
@@ -328,7 +352,7 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
             done_cv.wait(g, [&] { return n_written > must || sh.failed(); });
           }
           const auto t2 = Clock::now();
-          if (grc == THM_OK) grc = thm_batch_fetch(a, &s->res);
+          if (grc == THM_OK) grc = sh.step([&] { return thm_batch_fetch(a, &s->res); });
           if (grc == THM_OK && s->res.n_failed_reads) {
             // the reference aligns every read or panics; a read this build cannot take fails the run, by name
             uint64_t bad = 0;
@@ -365,9 +389,14 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
   // ---- stage 4: format (this thread, on the formatting threads of the writer) and write (one more thread), in input
   // order; two writer objects are used alternately, so that batch k + 1 is formatted while batch k is written ----
   {
+    // two writer objects, used alternately: the chunks of batch k are views into writer k & 1 and are still being
+    // written while batch k + 1 is formatted, so one object cannot stand in for both
     thm_writer* w2 = nullptr;
-    if (thm_writer_create(ix, format, n_threads, &w2) != THM_OK) w2 = nullptr;
-    thm_writer* ws[2] = {w, w2 ? w2 : w};
+    if (thm_writer_create(ix, format, n_threads, &w2) != THM_OK) {
+      w2 = nullptr;
+      sh.set(THM_ERR_OOM, "cannot create the second writer object");
+    }
+    thm_writer* ws[2] = {w, w2 ? w2 : w};  // (after a failure nothing is formatted any more: sh.failed())
     struct WriteJob {
       Slot* s = nullptr;
       uint64_t seq = 0;
@@ -447,7 +476,7 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
         const thm_read_batch rb = s->reads.view();
         const thm_batch_view& v = s->res;
         WriteJob& j = jobs[k];
-        const int wrc = thm::writer_format_chunks(ws[k], &rb, &v, j.chunks);
+        const int wrc = sh.step([&] { return thm::writer_format_chunks(ws[k], &rb, &v, j.chunks); });
         st.format_s += secs(t0, Clock::now());
         if (wrc != THM_OK) {
           sh.set(wrc, thm_last_error(nullptr));

@@ -126,7 +126,18 @@ static int fastq_fill_raw(thm_fastq* r, uint64_t max_reads, HostBatch& b, size_t
     } else if (!r->next_line(p, len)) {
       break;
     }
-    if (len == 0) continue;
+    if (len == 0) {
+      // empty lines are tolerated at the very end of the input only (the block parser of the parallel driver applies
+      // the same rule, so that both public paths accept the same files)
+      bool more = false;
+      while (r->next_line(p, len))
+        if (len) {
+          more = true;
+          break;
+        }
+      if (!more) break;
+      return fail(THM_ERR_FORMAT, "empty line inside the input before " + r->path + ":" + std::to_string(r->lineno));
+    }
     if (p[0] == '@') {
       put(b.names, nn, p + 1, len - 1);
       b.name_off.push_back(nn);
@@ -228,7 +239,7 @@ static inline size_t count_newlines(const char* p, size_t n) {
 }
 
 int fastq_next_raw_block(thm_fastq* r, uint64_t max_reads, std::vector<char>& raw, size_t& raw_len, uint64_t& n_lines,
-                         uint64_t& first_line) {
+                         uint64_t& first_line, bool& last_block) {
   const uint64_t want = max_reads * 4;
   raw_len = 0;
   n_lines = 0;
@@ -259,11 +270,15 @@ int fastq_next_raw_block(thm_fastq* r, uint64_t max_reads, std::vector<char>& ra
   }
   if (raw_len && raw[raw_len - 1] != '\n') n_lines++;  // a last line without its newline
   r->lineno += n_lines;
+  while (r->pos == r->end && refill(r)) {
+  }
+  last_block = r->pos == r->end;  // nothing behind this block
   if (r->io_err) return fail(THM_ERR_IO, r->io_msg);
   return THM_OK;
 }
 
-int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t first_line, HostBatch& b, std::string& err) {
+int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t first_line, bool last_block, HostBatch& b,
+                      std::string& err) {
   b.clear();
   const char* end = p + n;
   uint64_t line = first_line;
@@ -277,9 +292,11 @@ int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t
     while (len && s[len - 1] == '\r') len--;
     return true;
   };
-  // sizes are known up to a constant: one pass of appends into storage reserved once
-  if (b.bases.size() < n / 2 + 4096) b.bases.resize(n / 2 + 4096);
-  if (b.quals.size() < n / 2 + 4096) b.quals.resize(n / 2 + 4096);
+  // One pass of appends into storage reserved once.  Every byte copied below comes out of the block, so n bytes
+  // bound each array whatever the records look like (a well-formed block needs about n / 2, but a malformed one --
+  // one sequence line of most of the block, quality missing -- is copied before it is found out).
+  if (b.bases.size() < n + 4096) b.bases.resize(n + 4096);
+  if (b.quals.size() < n + 4096) b.quals.resize(n + 4096);
   if (b.names.size() < n + 4096) b.names.resize(n + 4096);
   size_t nb = 0, nq = 0, nn = 0;
   const char* s;
@@ -287,10 +304,10 @@ int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t
   while (next(s, len)) {
     const uint64_t at = line - 1;
     auto where = [&] { return path + ":" + std::to_string(at); };
-    if (len == 0) {  // empty lines are tolerated at the very end only
+    if (len == 0) {  // empty lines are tolerated at the very end of the INPUT only, not at the end of any block
       const char* t = p;
       while (t < end && (*t == '\n' || *t == '\r')) t++;
-      if (t == end) break;
+      if (t == end && last_block) break;
       err = "expected '@' at " + where();
       return THM_ERR_FORMAT;
     }
@@ -382,11 +399,12 @@ int32_t thm_debug_fastq_blocks(thm_fastq* r, uint64_t max_reads_per_block, thm_r
   for (;;) {
     size_t raw_len = 0;
     uint64_t n_lines = 0, first_line = 0;
-    int rc = thm::fastq_next_raw_block(r, max_reads_per_block, raw, raw_len, n_lines, first_line);
+    bool last_block = false;
+    int rc = thm::fastq_next_raw_block(r, max_reads_per_block, raw, raw_len, n_lines, first_line, last_block);
     if (rc != THM_OK) return rc;
     if (n_lines == 0) break;
     std::string err;
-    rc = thm::fastq_parse_block(raw.data(), raw_len, r->path, first_line, b, err);
+    rc = thm::fastq_parse_block(raw.data(), raw_len, r->path, first_line, last_block, b, err);
     if (rc != THM_OK) return fail(rc, err);
     const thm_read_batch v = b.view();
     for (uint64_t i = 0; i < v.n_reads; i++) {

@@ -43,11 +43,14 @@ int fastq_fill(thm_fastq* r, uint64_t max_reads, HostBatch& b);
 //   fastq_is_plain_fastq   the input starts with '@' (FASTA and anything else take the sequential parser)
 //   fastq_next_raw_block   up to max_reads records as raw bytes (`raw` reused; n_lines = 4 x records, except for a
 //                          truncated last record, which the block parser reports); 0 lines at the end of the input
-//   fastq_parse_block      strict 4-line records (CR LF tolerated, empty lines only at the very end of the input)
+//                          (last_block: nothing follows this block)
+//   fastq_parse_block      strict 4-line records (CR LF tolerated, empty lines only at the very end of the input,
+//                          i.e. at the end of the block for which last_block is set)
 bool fastq_is_plain_fastq(thm_fastq* r);
 int fastq_next_raw_block(thm_fastq* r, uint64_t max_reads, std::vector<char>& raw, size_t& raw_len, uint64_t& n_lines,
-                         uint64_t& first_line);
-int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t first_line, HostBatch& b, std::string& err);
+                         uint64_t& first_line, bool& last_block);
+int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t first_line, bool last_block, HostBatch& b,
+                      std::string& err);
 const std::string& fastq_path(const thm_fastq* r);
 
 // thm_writer_format_batch without the final concatenation: the text of the batch is

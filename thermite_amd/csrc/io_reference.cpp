@@ -494,9 +494,13 @@ static int32_t index_load_impl(const char* path, thm_index** out) {
   FILE* f = fopen(path, "rb");
   if (!f) return fail(THM_ERR_IO, std::string("cannot open ") + path);
   FileHeader h;
+  memset(&h, 0, sizeof h);
   if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, MAGIC, 8) != 0) {
     fclose(f);
-    return fail(THM_ERR_FORMAT, std::string(path) + " is not a THMIDX01 index file");
+    if (memcmp(h.magic, "THMIDX01", 8) == 0)
+      return fail(THM_ERR_FORMAT, std::string(path) + " is a THMIDX01 index file (the format before the suffix-array width field): "
+                                                       "rebuild it from the FASTA and GTF with this version");
+    return fail(THM_ERR_FORMAT, std::string(path) + " is not a " + std::string(MAGIC, 8) + " index file");
   }
   fseek(f, 0, SEEK_END);
   const uint64_t have = (uint64_t)ftell(f);
