@@ -67,17 +67,23 @@ def check_smems(w, bases, off, k):
 
 
 def check_align(w, bases, off, opts, n_threads=8):
-    a = w.aligner(opts)
-    a.reset_counters()
-    g = a.align_batch(bases, off)
+    """Both device paths against the oracle: the problem-parallel path (kernels_tpr.hip: thread-per-read control
+    kernel + wave-per-request DP kernel; what it leaves goes to the wave-per-read kernels) and the wave-per-read
+    kernels alone."""
     r = w.oix.align_batch(bases, off, opts, n_threads=n_threads)
     assert r.counters[15] == 0, "oracle saw reads where the reference would panic"
-    assert g.n_failed == 0 and g.status is None
-    assert_batch_equal(g, r)
-    c = a.counters()
-    assert np.array_equal(c[:10], r.counters[:10]) and c[12] == r.counters[12] and c[13] == r.counters[13], (c[:14], r.counters[:14])
-    assert c[10] <= r.counters[10] and c[11] <= r.counters[11]  # DP work: exact early exit computes fewer cells
-    a.close()
+    g = None
+    for no_tpr in (False, True):
+        a = w.aligner(opts)
+        a.debug_set_flags(no_tpr=no_tpr)
+        a.reset_counters()
+        g = a.align_batch(bases, off)
+        assert g.n_failed == 0 and g.status is None
+        assert_batch_equal(g, r)
+        c = a.counters()
+        assert np.array_equal(c[:10], r.counters[:10]) and c[12] == r.counters[12] and c[13] == r.counters[13], (no_tpr, c[:14], r.counters[:14])
+        assert c[10] <= r.counters[10] and c[11] <= r.counters[11], (no_tpr, c[:14], r.counters[:14])  # DP work: exact early exit computes fewer cells
+        a.close()
     return g
 
 

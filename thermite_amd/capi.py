@@ -230,6 +230,11 @@ def lib():
     if hasattr(L, "thm_debug_set_pool_caps"):
         L.thm_debug_set_pool_caps.restype = i32
         L.thm_debug_set_pool_caps.argtypes = [vp, u64, u64, u64, vp]
+    if hasattr(L, "thm_debug_set_flags"):
+        L.thm_debug_set_flags.restype = i32
+        L.thm_debug_set_flags.argtypes = [vp, C.c_uint32]
+        L.thm_debug_tpr_stats.restype = i32
+        L.thm_debug_tpr_stats.argtypes = [vp, vp]
     if hasattr(L, "thm_debug_calib_gather"):
         L.thm_debug_calib_gather.restype = i32
         L.thm_debug_calib_gather.argtypes = [vp, i32, u64, vp]
@@ -534,6 +539,17 @@ class Aligner:
         n = C.c_uint32()
         self._chk(lib().thm_debug_set_pool_caps(self.h, smem_cap, cand_cap, ops_cap, C.byref(n)))
         return n.value
+
+    def debug_set_flags(self, no_tpr=False, rounds=0):
+        """test / tuning hook: no_tpr = every read takes the wave-per-read kernels; rounds = request rounds of the
+        problem-parallel path (1..8, 0: keep)"""
+        self._chk(lib().thm_debug_set_flags(self.h, (1 if no_tpr else 0) | (int(rounds) << 8)))
+
+    def debug_tpr_stats(self):
+        """the last run's problem-parallel path (thm_debug_tpr_stats)"""
+        out = np.zeros(16, "<u8")
+        self._chk(lib().thm_debug_tpr_stats(self.h, _ptr(out)))
+        return out
 
     def debug_calib_gather(self, pattern, n_threads):
         """profiling hook: a gather of known size (see tools/calib_fetch.py); returns the bytes requested"""

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -162,6 +163,12 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
   a->ix = ix;
   a->device = device_id;
   a->opts = *opts;
+  {
+    const char* e = getenv("THM_TPR");  // 0: every read takes the wave-per-read kernels (A/B measurements)
+    if (e && e[0] == '0') a->use_tpr = false;
+    e = getenv("THM_TPR_ROUNDS");
+    if (e && atoi(e) >= 1 && atoi(e) <= TPR_MAX_ROUNDS) a->tpr_rounds = atoi(e);
+  }
   auto bail = [&](int code) {
     thm_aligner_free(a);
     return code;
@@ -195,7 +202,7 @@ void thm_aligner_free(thm_aligner* a) {
   if (a->stream) (void)hipStreamSynchronize(a->stream);
   if (a->stream2) (void)hipStreamSynchronize(a->stream2);
   DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->d_cursors, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4,
-                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->e_wcnt, &a->s_smems, &a->s_off, &a->s_cnt,
+                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->e_wcnt, &a->t_memos, &a->t_recs, &a->t_dpops, &a->t_qlist, &a->t_act[0], &a->t_act[1], &a->t_ctl, &a->s_smems, &a->s_off, &a->s_cnt,
                  &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops, &a->e_nalns,
                  &a->e_nalns64, &a->e_opbytes, &a->e_aln_off, &a->e_ops_off, &a->e_trace, &a->o_alns, &a->o_ops, &a->o_mems};
   for (DBuf* b : all) b->release();
@@ -381,6 +388,34 @@ int32_t thm_debug_set_pool_caps(thm_aligner* a, uint64_t smem_cap, uint64_t cand
   a->dbg_ops_cap = ops_cap;
   a->smem_cap = a->cand_cap = a->cand_ops_cap = 0;
   if (n_replays) *n_replays = a->n_replays;
+  return THM_OK;
+}
+
+// test / tuning hook.  flags bit 0: 1 = the problem-parallel path (kernels_tpr.hip) is off: every read takes the
+// wave-per-read kernels (the parity tests run both ways); bits 8..11: rounds of requests (0: keep).
+// thm_debug_tpr_stats: 16 words of the last run -- [0] reads of the fast class left to the wave-per-read kernel,
+// [1..7] why (1 band, 2 grid, 3 lift, 6 capacity, 7 other), [8] DP requests, [9] DP op bytes reserved,
+// [10..13] requests by band class, [14] reads still waiting when the rounds ran out.
+int32_t thm_debug_set_flags(thm_aligner* a, uint32_t flags) {
+  if (!a) return THM_ERR_INVALID_ARG;
+  a->use_tpr = (flags & 1u) == 0;
+  const int r = (int)((flags >> 8) & 15u);
+  if (r >= 1 && r <= TPR_MAX_ROUNDS) a->tpr_rounds = r;
+  return THM_OK;
+}
+int32_t thm_debug_tpr_stats(thm_aligner* a, uint64_t stats[16]) {
+  if (!a || !stats) return THM_ERR_INVALID_ARG;
+  memset(stats, 0, 128);
+  if (!a->t_ctl.p) return THM_OK;
+  HIPCHK(a, hipSetDevice(a->device));
+  HIPCHK(a, hipStreamSynchronize(a->stream));
+  unsigned long long c[32];
+  HIPCHK(a, hipMemcpy(c, a->t_ctl.p, sizeof c, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 8; k++) stats[k] = c[TPRC_STATS + k];
+  stats[8] = c[TPRC_REC_CUR];
+  stats[9] = c[TPRC_DPO_CUR];
+  for (int k = 0; k < 4; k++) stats[10 + k] = c[TPRC_Q_CUR + k];
+  stats[14] = c[TPRC_N_ACT + a->tpr_rounds + 1];
   return THM_OK;
 }
 

@@ -111,6 +111,12 @@ struct thm_aligner {
   uint64_t smem_cap = 0;
   // extension
   DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace, e_slow, e_recs, e_wcnt;
+  // Extension problems as the unit of wavefront work (kernels_tpr.hip: thread-per-read control kernel + wave-per-request
+  // DP kernel, in rounds), ahead of the wave-per-read kernels, which take what is left.  THM_TPR=0 or
+  // thm_debug_set_flags turn it off (every read then takes the wave-per-read path); THM_TPR_ROUNDS = 1..8.
+  DBuf t_memos, t_recs, t_dpops, t_qlist, t_act[2], t_ctl;
+  bool use_tpr = true;
+  int tpr_rounds = 8;
   uint64_t n_slow_host = 0;     // reads of the slow class in the last enqueue (host count)
   uint32_t fast_max_len = 0, slow_max_len = 0;
   uint64_t cand_cap = 0, cand_ops_cap = 0;

@@ -747,7 +747,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
   // its own contiguous share of the batch, and a wave that finds its counter exhausted moves on to
   // the next one.
   const bool list_only = GS || p.list_only != 0;
-  const unsigned n_total = list_only ? 0u : (unsigned)p.reads.n_reads;
+  const unsigned n_total = (list_only || p.skip_scan != 0) ? 0u : (unsigned)p.reads.n_reads;
   const unsigned q_share = (n_total + EXT_NQ - 1) / EXT_NQ;
   unsigned my_q = wave_global % EXT_NQ, q_tried = 0;
   // Longest jobs first: reads with many seed hits (repeats; up to a few hundred hits, i.e.

@@ -237,6 +237,7 @@ struct ExtendParamsT {
   uint32_t max_bw;
   uint32_t mk_cap;        // intron markers per alignment
   uint32_t list_only;     // 1: only the reads of the list (any-width kernel)
+  uint32_t skip_scan;     // 1: the wave-per-read kernel takes its lists only (the rest of the batch went through kernels_tpr.hip)
   unsigned long long* trace_scratch;  // fast kernel: [waves in the grid * extend_trace_scratch_bytes / 8] (unused when cpl == 1)
   uint8_t* slow_scratch;              // any-width kernel: [waves in the grid * slow_scratch_per_wave]
   uint64_t slow_scratch_per_wave;
@@ -254,6 +255,78 @@ inline bool team_fits_lds(size_t lds4) { return lds4 / 4 * TEAM_WAVES + TEAM_STA
 // team = true: the workgroup-per-read variant for reads with very many hits (cpl 1 or 2 only; TEAM_WAVES waves per workgroup)
 hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s, bool team = false);
 hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s, bool team = false);
+// ---- extension problems as the unit of wavefront work (kernels_tpr.hip) ----
+// One SwgExtend::extend call that needs a DP: written by the control kernel (thread per read), computed by the DP
+// kernel (wave per record), read back by the control kernel in the next round.
+struct DpRec {
+  const uint8_t* x0;  // x[t] = x0[t * dir]: the read as the extension walks it
+  const uint8_t* y0;  // y[t] = y0[t * dir]: the target (text or transcript sequence)
+  uint64_t ops_off;   // room for xlen + ylen op bytes in the DP op pool; the DP kernel leaves the ops in traceback order
+  uint16_t xlen, ylen, bw, xd;
+  int8_t dir;         // +1: right extension, -1: left extension
+  uint8_t cls;        // band slots per lane the problem needs: ceil(min(2 bw + 1, xlen + 1) / 64), 1..4
+  uint16_t pad_;
+  uint32_t read;      // (diagnostics)
+  // result
+  int32_t score;
+  uint16_t xend, yend, nops;
+  uint16_t done;      // 0: requested, 1: computed
+  uint32_t cells, cols;  // DP work of the result (THM_CNT_DP_CELLS / _COLS when a finished read used it)
+  uint32_t pad2_;
+};
+static_assert(sizeof(DpRec) == 64, "DpRec layout");
+constexpr int TPR_MAX_ROUNDS = 8;  // rounds of requests one read may take (then: the wave-per-read kernel)
+// the records of a read, by round: ordinal o of the read's replay is record base[k] + (o - cnt[0] - .. - cnt[k-1])
+struct ReadMemo {
+  uint32_t base[TPR_MAX_ROUNDS];
+  uint8_t cnt[TPR_MAX_ROUNDS];
+  uint8_t n_rounds;
+  uint8_t pad_[7];
+};
+static_assert(sizeof(ReadMemo) == 48, "ReadMemo layout");
+template <class C>
+struct TprParamsT {
+  ReadRecT<C>* recs_rw;   // = ExtendParamsT::read_recs, writable: a finished read gets len = 0xFFFFFFFF (skipped by every later kernel)
+  ReadMemo* memos;        // [n_reads]
+  DpRec* recs;
+  uint64_t rec_cap;
+  unsigned long long* rec_cursor;
+  uint8_t* dp_ops;
+  uint64_t dp_ops_cap;
+  unsigned long long* dp_ops_cursor;
+  uint32_t* q_list;            // [4][q_stride] record indices by band class, appended to over the rounds
+  uint64_t q_stride;
+  unsigned long long* q_cur;   // [4] ends of the lists
+  const uint32_t* act_in;      // reads of this round (round 0: all reads, no list)
+  const unsigned long long* n_act_in;
+  uint32_t* act_out;           // reads that wait for results: the next round's list
+  unsigned long long* n_act_out;
+  unsigned long long* bail;    // reads left to the wave-per-read kernel: appended to its list (ExtendParamsT::heavy)
+  unsigned long long* bail_count;
+  uint32_t round;
+  uint32_t last_round;         // 1: no DP launch follows; a read that still needs results goes to the wave-per-read kernel
+  unsigned long long* stats;   // 8 words (may be null): [0] reads left to the wave-per-read kernel, [1..7] why
+};
+struct DpParams {
+  DpRec* recs;
+  uint8_t* dp_ops;
+  const uint32_t* q_list;
+  uint64_t q_stride;
+  const unsigned long long* q_cur;   // [4]
+  const unsigned long long* q_done;  // [4] ends of the lists as of the previous round
+  unsigned int* work;                // work counter of this launch (zeroed before the run)
+  int* fault;
+  uint32_t x_cap, y_cap;             // per-wave LDS bytes for x and y (multiples of 16, 64 bytes of slack each)
+};
+size_t extend_dp_lds_bytes(uint32_t x_cap, uint32_t y_cap, int cpl);  // per workgroup (4 waves)
+hipError_t launch_extend_ctl(const ExtendParamsT<uint32_t>& p, const TprParamsT<uint32_t>& tp, int n_blocks, hipStream_t s);
+hipError_t launch_extend_ctl(const ExtendParamsT<uint64_t>& p, const TprParamsT<uint64_t>& tp, int n_blocks, hipStream_t s);
+hipError_t launch_extend_dp(const DpParams& p, int cpl, int n_blocks, hipStream_t s);
+constexpr int TPR_CTL_BLOCKS_PER_CU = 4, TPR_DP_BLOCKS_PER_CU = 8;
+// layout of the small control block of a run (u64 words; zeroed before the run)
+enum { TPRC_REC_CUR = 0, TPRC_DPO_CUR = 1, TPRC_Q_CUR = 2, TPRC_Q_DONE = 6, TPRC_N_ACT = 10 /* [TPR_MAX_ROUNDS + 2] */, TPRC_STATS = 24 /* [8] */,
+       TPRC_WORK_BYTES = 512 /* u32 work counters, 64 bytes apart: [round][class] */ };
+constexpr size_t TPRC_BYTES = TPRC_WORK_BYTES + (size_t)(TPR_MAX_ROUNDS + 1) * 4 * 64;
 
 struct CompactParams {
   uint64_t n_reads;

@@ -270,10 +270,74 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     slow_waves = (slow_waves + 3) / 4 * 4;
   }
   const uint64_t main_rows = (uint64_t)ext_blocks * 4, team_rows = team_ok ? (uint64_t)a->n_cu * TEAM_WAVES : 0;
-  const uint64_t n_rows = main_rows + team_rows + slow_waves;
+  // ---- extension problems as the unit of wavefront work (kernels_tpr.hip): rounds of [control kernel, thread per
+  // read | DP kernel, wave per request]; what it cannot take goes on the wave-per-read kernel's list ----
+  const bool tpr = a->use_tpr && n > 0 && cpl <= 4;
+  const int ctl_blocks = tpr ? (int)std::min<uint64_t>((n + 255) / 256, (uint64_t)a->n_cu * TPR_CTL_BLOCKS_PER_CU) : 0;
+  const int dp_blocks = tpr ? a->n_cu * TPR_DP_BLOCKS_PER_CU : 0;
+  const uint64_t tpr_rows = (uint64_t)ctl_blocks;
+  const uint64_t n_rows = main_rows + team_rows + slow_waves + tpr_rows;
   HIPCHK(a, a->e_wcnt.ensure(n_rows * THM_N_COUNTERS * 8 + 64));
   HIPCHK(a, hipMemsetAsync(a->e_wcnt.p, 0, n_rows * THM_N_COUNTERS * 8, s));
   ep.wave_counters = a->e_wcnt.as<unsigned long long>();
+  ep.skip_scan = 0;
+  if (tpr) {
+    const uint64_t rec_cap = std::min<uint64_t>(4 * n + 65536, 64ull << 20);
+    const uint64_t dpo_cap = rec_cap * 192;
+    HIPCHK(a, a->t_memos.ensure(n * sizeof(ReadMemo) + 64));
+    HIPCHK(a, a->t_recs.ensure(rec_cap * sizeof(DpRec) + 64));
+    HIPCHK(a, a->t_dpops.ensure(dpo_cap + 64));
+    HIPCHK(a, a->t_qlist.ensure(4 * rec_cap * 4 + 64));
+    HIPCHK(a, a->t_act[0].ensure(n * 4 + 64));
+    HIPCHK(a, a->t_act[1].ensure(n * 4 + 64));
+    HIPCHK(a, a->t_ctl.ensure(TPRC_BYTES));
+    HIPCHK(a, hipMemsetAsync(a->t_ctl.p, 0, TPRC_BYTES, s));
+    unsigned long long* ctl = a->t_ctl.as<unsigned long long>();
+    TprParamsT<C> tq;
+    tq.recs_rw = a->e_recs.as<ReadRecT<C>>();
+    tq.memos = a->t_memos.as<ReadMemo>();
+    tq.recs = a->t_recs.as<DpRec>();
+    tq.rec_cap = rec_cap;
+    tq.rec_cursor = ctl + TPRC_REC_CUR;
+    tq.dp_ops = a->t_dpops.as<uint8_t>();
+    tq.dp_ops_cap = dpo_cap;
+    tq.dp_ops_cursor = ctl + TPRC_DPO_CUR;
+    tq.q_list = a->t_qlist.as<uint32_t>();
+    tq.q_stride = rec_cap;
+    tq.q_cur = ctl + TPRC_Q_CUR;
+    tq.bail = ep.heavy == nullptr ? nullptr : const_cast<unsigned long long*>(ep.heavy);
+    tq.bail_count = const_cast<unsigned long long*>(ep.heavy_count);
+    tq.stats = ctl + TPRC_STATS;
+    ExtendParamsT<C> zp = ep;
+    zp.wave_counters = ep.wave_counters + (main_rows + team_rows + slow_waves) * THM_N_COUNTERS;
+    DpParams dq;
+    dq.recs = tq.recs;
+    dq.dp_ops = tq.dp_ops;
+    dq.q_list = tq.q_list;
+    dq.q_stride = tq.q_stride;
+    dq.q_cur = ctl + TPRC_Q_CUR;
+    dq.q_done = ctl + TPRC_Q_DONE;
+    dq.fault = ep.fault;
+    dq.x_cap = (cls.fast_len + 64u + 15u) & ~15u;
+    dq.y_cap = (cls.fast_len + cls.fast_bw + 2u + 64u + 15u) & ~15u;
+    const int n_rounds = a->tpr_rounds;  // rounds of requests a read may take (then: the wave-per-read kernel)
+    for (int r = 0; r <= n_rounds; r++) {
+      tq.round = (uint32_t)r;
+      tq.act_in = a->t_act[r & 1].as<uint32_t>();
+      tq.n_act_in = ctl + TPRC_N_ACT + r;
+      tq.act_out = a->t_act[(r + 1) & 1].as<uint32_t>();
+      tq.n_act_out = ctl + TPRC_N_ACT + r + 1;
+      tq.last_round = r == n_rounds ? 1u : 0u;
+      HIPCHK(a, launch_extend_ctl(zp, tq, ctl_blocks, s));
+      if (r == n_rounds) break;
+      for (int c = 1; c <= cpl; c++) {
+        dq.work = (unsigned int*)((uint8_t*)a->t_ctl.p + TPRC_WORK_BYTES + ((size_t)r * 4 + (size_t)(c - 1)) * 64);
+        HIPCHK(a, launch_extend_dp(dq, c, dp_blocks, s));
+      }
+      HIPCHK(a, hipMemcpyAsync(ctl + TPRC_Q_DONE, ctl + TPRC_Q_CUR, 32, hipMemcpyDeviceToDevice, s));
+    }
+    ep.skip_scan = 1;
+  }
   if (team_ok) {
     ExtendParamsT<C> tp = ep;
     tp.list_only = 1;

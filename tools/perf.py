@@ -33,6 +33,11 @@ for name, opts in (("ci", capi.CI_OPTS), ("default", capi.DEFAULT_OPTS)):
     runs = K + 2
     print("         per read: smems %.2f hits %.2f swg_calls %.2f cols %.1f cells %.0f alns %.2f win_bytes %.0f" % tuple(
         c[k] / (n * runs) for k in ("smems", "hits", "swg_calls", "dp_cols", "dp_cells", "alns", "window_bytes")), flush=True)
+    if hasattr(a, "debug_tpr_stats"):
+        es = a.debug_tpr_stats()
+        print("         problem-parallel path: %d DP requests (by band class %s), %d reads left to the wave-per-read kernel "
+              "(band %d grid %d lift %d capacity %d other %d), %d still waiting after the last round" % (
+                  es[8], es[10:14].tolist(), es[0], es[1], es[2], es[3], es[6], es[7], es[14]), flush=True)
     pr = a.debug_prof()
     if pr.sum() > 0:
         names = ["setup", "stage", "dp", "traceback", "tree", "txprep", "lift", "emit", "final", "other"]
