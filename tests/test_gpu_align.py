@@ -75,7 +75,7 @@ def check_align(w, bases, off, opts, n_threads=8):
     g = None
     for no_tpr in (False, True):
         a = w.aligner(opts)
-        a.debug_set_flags(no_tpr=no_tpr)
+        a.debug_set_flags(tpr=not no_tpr)
         a.reset_counters()
         g = a.align_batch(bases, off)
         assert g.n_failed == 0 and g.status is None

@@ -540,10 +540,10 @@ class Aligner:
         self._chk(lib().thm_debug_set_pool_caps(self.h, smem_cap, cand_cap, ops_cap, C.byref(n)))
         return n.value
 
-    def debug_set_flags(self, no_tpr=False, rounds=0):
-        """test / tuning hook: no_tpr = every read takes the wave-per-read kernels; rounds = request rounds of the
-        problem-parallel path (1..8, 0: keep)"""
-        self._chk(lib().thm_debug_set_flags(self.h, (1 if no_tpr else 0) | (int(rounds) << 8)))
+    def debug_set_flags(self, tpr=None, rounds=0):
+        """test / tuning hook: tpr = False: every read takes the wave-per-read kernels, True: the problem-parallel path
+        in front of them (None: keep); rounds = its request rounds (1..8, 0: keep)"""
+        self._chk(lib().thm_debug_set_flags(self.h, (0 if tpr is None else (2 if tpr else 1)) | (int(rounds) << 8)))
 
     def debug_tpr_stats(self):
         """the last run's problem-parallel path (thm_debug_tpr_stats)"""

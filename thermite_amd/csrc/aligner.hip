@@ -164,8 +164,9 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
   a->device = device_id;
   a->opts = *opts;
   {
-    const char* e = getenv("THM_TPR");  // 0: every read takes the wave-per-read kernels (A/B measurements)
+    const char* e = getenv("THM_TPR");  // 0 / 1: the problem-parallel path off / on (A/B measurements)
     if (e && e[0] == '0') a->use_tpr = false;
+    if (e && e[0] == '1') a->use_tpr = true;
     e = getenv("THM_TPR_ROUNDS");
     if (e && atoi(e) >= 1 && atoi(e) <= TPR_MAX_ROUNDS) a->tpr_rounds = atoi(e);
   }
@@ -181,6 +182,8 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
   for (auto& e : a->ev)
     if (hipEventCreate(&e) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&a->stream3, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&a->ev_join3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming) != hipSuccess)
     return bail(fail(nullptr, THM_ERR_HIP, "second stream / events: creation failed"));
@@ -201,8 +204,9 @@ void thm_aligner_free(thm_aligner* a) {
   (void)hipSetDevice(a->device);
   if (a->stream) (void)hipStreamSynchronize(a->stream);
   if (a->stream2) (void)hipStreamSynchronize(a->stream2);
+  if (a->stream3) (void)hipStreamSynchronize(a->stream3);
   DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->d_cursors, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4,
-                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->e_wcnt, &a->t_memos, &a->t_recs, &a->t_dpops, &a->t_qlist, &a->t_act[0], &a->t_act[1], &a->t_ctl, &a->s_smems, &a->s_off, &a->s_cnt,
+                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->e_wcnt, &a->t_memos, &a->t_recs, &a->t_dpops, &a->t_qlist, &a->t_act[0], &a->t_act[1], &a->t_ctl, &a->t_bail, &a->t_queue2, &a->t_trace, &a->s_smems, &a->s_off, &a->s_cnt,
                  &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops, &a->e_nalns,
                  &a->e_nalns64, &a->e_opbytes, &a->e_aln_off, &a->e_ops_off, &a->e_trace, &a->o_alns, &a->o_ops, &a->o_mems};
   for (DBuf* b : all) b->release();
@@ -216,6 +220,8 @@ void thm_aligner_free(thm_aligner* a) {
     if (e) (void)hipEventDestroy(e);
   if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
   if (a->ev_join) (void)hipEventDestroy(a->ev_join);
+  if (a->ev_join3) (void)hipEventDestroy(a->ev_join3);
+  if (a->stream3) (void)hipStreamDestroy(a->stream3);
   if (a->stream2) (void)hipStreamDestroy(a->stream2);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   delete a;
@@ -391,14 +397,15 @@ int32_t thm_debug_set_pool_caps(thm_aligner* a, uint64_t smem_cap, uint64_t cand
   return THM_OK;
 }
 
-// test / tuning hook.  flags bit 0: 1 = the problem-parallel path (kernels_tpr.hip) is off: every read takes the
-// wave-per-read kernels (the parity tests run both ways); bits 8..11: rounds of requests (0: keep).
+// test / tuning hook.  flags bit 0: the problem-parallel path (kernels_tpr.hip) off -- every read takes the wave-per-read
+// kernels; bit 1: on (the parity tests run both ways); bits 8..11: rounds of requests (0: keep).
 // thm_debug_tpr_stats: 16 words of the last run -- [0] reads of the fast class left to the wave-per-read kernel,
 // [1..7] why (1 band, 2 grid, 3 lift, 6 capacity, 7 other), [8] DP requests, [9] DP op bytes reserved,
 // [10..13] requests by band class, [14] reads still waiting when the rounds ran out.
 int32_t thm_debug_set_flags(thm_aligner* a, uint32_t flags) {
   if (!a) return THM_ERR_INVALID_ARG;
-  a->use_tpr = (flags & 1u) == 0;
+  if (flags & 1u) a->use_tpr = false;
+  if (flags & 2u) a->use_tpr = true;
   const int r = (int)((flags >> 8) & 15u);
   if (r >= 1 && r <= TPR_MAX_ROUNDS) a->tpr_rounds = r;
   return THM_OK;

@@ -88,6 +88,8 @@ struct thm_aligner {
   int n_cu = 256;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // the team kernel runs beside the wave-per-read kernel
+  hipStream_t stream3 = nullptr;  // ... and both beside the rounds of the problem-parallel path
+  hipEvent_t ev_join3 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   thm_align_opts opts;
   std::string err;
@@ -114,8 +116,8 @@ struct thm_aligner {
   // Extension problems as the unit of wavefront work (kernels_tpr.hip: thread-per-read control kernel + wave-per-request
   // DP kernel, in rounds), ahead of the wave-per-read kernels, which take what is left.  THM_TPR=0 or
   // thm_debug_set_flags turn it off (every read then takes the wave-per-read path); THM_TPR_ROUNDS = 1..8.
-  DBuf t_memos, t_recs, t_dpops, t_qlist, t_act[2], t_ctl;
-  bool use_tpr = true;
+  DBuf t_memos, t_recs, t_dpops, t_qlist, t_act[2], t_ctl, t_bail, t_queue2, t_trace;
+  bool use_tpr = false;  // (until the path is the faster one on the headline workload)
   int tpr_rounds = 8;
   uint64_t n_slow_host = 0;     // reads of the slow class in the last enqueue (host count)
   uint32_t fast_max_len = 0, slow_max_len = 0;

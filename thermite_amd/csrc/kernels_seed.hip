@@ -755,9 +755,12 @@ __global__ __launch_bounds__(256) void plan_kernel(PlanParams p) {
     p.read_n_alns[r] = 0;
     p.read_op_bytes[r] = 0;
   }
-  const uint64_t team_thr = min((uint64_t)TEAM_HITS, max((uint64_t)TEAM_MIN_HITS, *p.total_hits / max(p.team_div, 1u)));
+  // (with the problem-parallel path in front, the wave-per-read kernel has little else to do: every read that path does
+  // not take and the team kernel can, is the team's)
+  const uint64_t team_thr = p.tpr_max_hits ? (uint64_t)max(p.tpr_max_hits, TEAM_MIN_HITS)
+                                           : min((uint64_t)TEAM_HITS, max((uint64_t)TEAM_MIN_HITS, *p.total_hits / max(p.team_div, 1u)));
   const bool team = fast && p.team_ok && hits >= team_thr && hits <= TEAM_MAX_HITS;
-  block_append(fast && !team && hits >= HEAVY_HITS, r, p.heavy, &p.counts[2]);
+  block_append(fast && !team && hits >= (p.tpr_max_hits ? (uint64_t)p.tpr_max_hits : (uint64_t)HEAVY_HITS), r, p.heavy, &p.counts[2]);
   block_append(slow, r, p.slow, &p.counts[5]);
   block_append(team, r, p.team, &p.counts[7]);
 }

@@ -20,11 +20,17 @@
 // src/aligner.rs:143-175), so a read needs the results of hit k before it can state the problems of hit k + 1: the
 // two kernels alternate in ROUNDS.  The control kernel keeps no state between rounds but the results themselves: in
 // every round it replays the read from its first hit (thread-level work: cheap), taking the DP results of earlier
-// rounds from the read's memo, until it meets a hit whose results are missing; it requests ALL extension problems
-// of that hit (genome window and every transcript target) and goes to sleep.  A read whose replay gets through its
-// last hit is finished: final filters, serialisation, done.  Reads that exceed one of the small fixed capacities of
-// this path (rounds, candidates, grid entries, introns) and reads with HEAVY_HITS hits and more go on the list of
-// the wave-per-read kernel, which remains the general path.
+// rounds from the read's memo, until it meets a hit whose results are missing; it requests the extension problems
+// of that hit (genome window and every transcript target) and goes to sleep.  The carried state changes only when a
+// hit beats the best score so far -- a handful of times per read, early -- so once a read has an accepted candidate the
+// request covers ALL its remaining hits under the state in force (the scheme of the team kernel, kernels_extend.hip):
+// the next replay takes those results for as long as the state really stays what it was and asks again, under the
+// new state, from the first hit behind a change.  Exact: every result that is used was computed under exactly the
+// band and X-drop the sequential loop has at that hit.  A read whose replay gets through its last hit is finished:
+// final filters, serialisation, done.  Reads that exceed one of the small fixed capacities of this path (rounds,
+// candidates, grid entries, introns) go on the lists of the wave-per-read kernels, which remain the general path;
+// reads with TPR_MAX_HITS hits and more are theirs from the start (a thread replaying thousands of hits would be the
+// tail of the launch).
 //
 // Exactness.  Every extend() call gets the inputs the reference gives it (x, y, band, X-drop; y cut to the
 // |x| + bw + 1 reachable columns) and is computed by the same device code as before.  Two
@@ -47,9 +53,10 @@ namespace dev {
 
 namespace {
 
-constexpr int TPR_KEEP = 4;      // accepted candidates a thread keeps book of
+constexpr int TPR_KEEP = 8;      // accepted candidates a thread keeps book of
 constexpr int TPR_MAX_ENT = 24;  // exon-grid candidates of one query a thread walks
 constexpr int TPR_MAX_MK = 4;    // introns of one alignment
+constexpr int TPR_MAX_PEND = 24;  // extension problems one read may ask for in one round
 #ifndef THM_TPR_CTL_MINW
 #define THM_TPR_CTL_MINW 4
 #endif
@@ -71,9 +78,24 @@ __device__ __forceinline__ uint64_t ld8(const uint8_t* p) {
   __builtin_memcpy(&v, p, 8);  // one global_load_dwordx2 (unaligned access is enabled for global memory)
   return v;
 }
+struct U16 {
+  uint64_t lo, hi;
+};
+__device__ __forceinline__ U16 ld16(const uint8_t* p) {
+  U16 v;
+  __builtin_memcpy(&v, p, 16);  // one global_load_dwordx4
+  return v;
+}
 // leading positions t < n with a[t] == b[t]; touches nothing outside [a, a + n) and [b, b + n)
 __device__ __forceinline__ int match_fwd(const uint8_t* a, const uint8_t* b, int n) {
   int t = 0;
+  while (t + 16 <= n) {
+    const U16 x = ld16(a + t), y = ld16(b + t);
+    const uint64_t d0 = x.lo ^ y.lo, d1 = x.hi ^ y.hi;
+    if (d0) return t + (int)(__builtin_ctzll(d0) >> 3);
+    if (d1) return t + 8 + (int)(__builtin_ctzll(d1) >> 3);
+    t += 16;
+  }
   while (t + 8 <= n) {
     const uint64_t d = ld8(a + t) ^ ld8(b + t);
     if (d) return t + (int)(__builtin_ctzll(d) >> 3);
@@ -85,6 +107,13 @@ __device__ __forceinline__ int match_fwd(const uint8_t* a, const uint8_t* b, int
 // positions t < n with a[-1 - t] == b[-1 - t], walking backwards; touches nothing outside [a - n, a) and [b - n, b)
 __device__ __forceinline__ int match_bwd(const uint8_t* a, const uint8_t* b, int n) {
   int t = 0;
+  while (t + 16 <= n) {
+    const U16 x = ld16(a - 16 - t), y = ld16(b - 16 - t);
+    const uint64_t d0 = x.lo ^ y.lo, d1 = x.hi ^ y.hi;
+    if (d1) return t + (int)(__builtin_clzll(d1) >> 3);
+    if (d0) return t + 8 + (int)(__builtin_clzll(d0) >> 3);
+    t += 16;
+  }
   while (t + 8 <= n) {
     const uint64_t d = ld8(a - 8 - t) ^ ld8(b - 8 - t);
     if (d) return t + (int)(__builtin_clzll(d) >> 3);
@@ -92,6 +121,36 @@ __device__ __forceinline__ int match_bwd(const uint8_t* a, const uint8_t* b, int
   }
   while (t < n && a[-1 - t] == b[-1 - t]) t++;
   return t;
+}
+
+// a[0 .. n) == b[0 .. n), and (through `uniform`) whether every a[t] equals the byte c; touches nothing outside the ranges
+__device__ __forceinline__ bool equal_and_uniform(const uint8_t* a, const uint8_t* b, int n, uint8_t c, bool& uniform) {
+  const uint64_t splat = 0x0101010101010101ull * (uint64_t)c;
+  uint64_t diff = 0, nonu = 0;
+  int t = 0;
+  while (t + 16 <= n) {
+    const U16 x = ld16(a + t), y = ld16(b + t);
+    diff |= (x.lo ^ y.lo) | (x.hi ^ y.hi);
+    nonu |= (x.lo ^ splat) | (x.hi ^ splat);
+    if (diff) {
+      uniform = false;
+      return false;
+    }
+    t += 16;
+  }
+  while (t + 8 <= n) {
+    const uint64_t x = ld8(a + t), y = ld8(b + t);
+    diff |= x ^ y;
+    nonu |= x ^ splat;
+    t += 8;
+  }
+  while (t < n) {
+    diff |= (uint64_t)(a[t] ^ b[t]);
+    nonu |= (uint64_t)(a[t] ^ c);
+    t++;
+  }
+  uniform = nonu == 0;
+  return diff == 0;
 }
 
 // One SwgExtend::extend call as the control kernel sees it.  rec < 0: the result is known in closed form (ops in
@@ -123,9 +182,9 @@ __device__ __forceinline__ Side side_classify(const uint8_t* x0, const uint8_t* 
   const uint8_t* xa = dir > 0 ? x0 + 1 : x0 - n1;
   const uint8_t* ya = dir > 0 ? y0 + 1 : y0 - n1;
   // swg_one_mismatch_shortcut: |x| >= 3, |y| >= |x|, x_drop >= 1, x[0] != y[0], x[1..] == y[1..|x|), x not one repeated base
-  if (xlen >= 3 && ylen >= (long long)xlen && xd >= 1 && match_fwd(xa, ya, n1) == n1) {
-    const uint8_t* xh = dir > 0 ? x0 : x0 - n1;  // x[t] == x[t + 1] for all t: one repeated base
-    if (match_fwd(xh, xh + 1, n1) != n1) {
+  if (xlen >= 3 && ylen >= (long long)xlen && xd >= 1) {
+    bool uniform;  // x[1..] all equal to x[0]: one repeated base
+    if (equal_and_uniform(xa, ya, n1, x0[0], uniform) && !uniform) {
       s.known = true;
       s.score = s.ub = xlen - 2;
       s.xend = s.yend = s.n = xlen;
@@ -161,6 +220,16 @@ __device__ __forceinline__ void idx_to_ref_thread(const IX& ix, C idx, RefRecT<C
   }
   id = lo;
 }
+
+// an extension problem whose result is missing, until the workgroup's allocation has given it a record
+struct Pend {
+  const uint8_t* x0;
+  const uint8_t* y0;
+  uint16_t xlen, ylen;
+  int8_t dir;
+  uint8_t cls;
+  uint16_t pad_;
+};
 
 // what the kernel keeps of an accepted candidate until the read is finished
 struct TCand {
@@ -248,8 +317,10 @@ __device__ __forceinline__ void emit_stream(uint8_t* o, int total, const PathVie
 //   round 0: the reads are 0 .. n_reads; later rounds: the list the round before left (tp.act_in).
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int NALLOC = 9;  // cand op bytes, records, DP op bytes, sleepers, bails, queue slots of the four band classes
-enum { A_OPS = 0, A_REC = 1, A_DPO = 2, A_ACT = 3, A_BAIL = 4, A_Q0 = 5 };
+// quantities a workgroup allocates in one go: cand op bytes, records, DP op bytes, sleepers, bails to the heavy list,
+// bails to the team list, queue slots of the four band classes
+constexpr int NALLOC = 10;
+enum { A_OPS = 0, A_REC = 1, A_DPO = 2, A_ACT = 3, A_BAIL = 4, A_BAILT = 5, A_Q0 = 6 };
 
 // everything one walk over a hit's extension problems produces
 template <class S, class C>
@@ -261,9 +332,6 @@ struct HitOut {
   uint32_t ref_id;
   unsigned calls, win;
   unsigned long long cells, cols;  // DP work of the results the hit used
-  unsigned ord_end;          // ordinal behind the hit's last request
-  unsigned m_req, m_ops;     // mode 1: requests of the hit, bytes of DP op room
-  unsigned m_cls[4];         // ... by band class (without a dead genome problem's)
   int why;
 };
 }  // namespace
@@ -281,7 +349,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
   if (threadIdx.x < 8) s_stats[threadIdx.x] = 0;
   __syncthreads();
   const auto& ix = p.ix;
-  const uint64_t n_items = tp.round == 0 ? p.reads.n_reads : (uint64_t)*tp.n_act_in;
+  const uint64_t n_items = (uint64_t)*tp.n_act_in;  // round 0: the reads of this path by descending hit count (tpr_order_kernel)
   const uint64_t gsz = (uint64_t)gridDim.x * 256;
   const uint64_t n_iter = (n_items + gsz - 1) / gsz;
   const bool dead_run = *p.fault_seed != 0;  // SMEM pool overflow: the host grows the pool and replays the batch
@@ -289,8 +357,8 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
   for (uint64_t it = 0; it < n_iter; it++) {
     const uint64_t item = it * gsz + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     // (a slot of the list whose read went to the wave-per-read kernel after all holds 0xFFFFFFFF)
-    const uint64_t idx_raw = item < n_items ? (tp.round == 0 ? item : (uint64_t)tp.act_in[item]) : 0;
-    const bool active = item < n_items && !dead_run && !(tp.round != 0 && idx_raw == 0xFFFFFFFFull);
+    const uint64_t idx_raw = item < n_items ? (uint64_t)tp.act_in[item] : 0;
+    const bool active = item < n_items && !dead_run && idx_raw != 0xFFFFFFFFull;
     const uint64_t idx = active ? idx_raw : 0;
     bool done = false, sleep = false, bail = false;
     int why = 0;  // statistics only
@@ -303,41 +371,51 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
     int L = 0;
     ReadMemo memo;
     memo.n_rounds = 0;
-    unsigned avail = 0;  // DP results the memo holds
-    // the frontier hit (the first one whose results are missing): its requests are written after the workgroup's allocation
-    uint32_t f_si = 0;
-    C f_rr = 0;
+    // replay position in the memo: the round whose records the walk reads, the next record of it, and whether the
+    // state in force is still the one the round was requested under
+    int k_round = -1;
+    unsigned ord_r = 0;
+    bool round_ok = false;
+    // the frontier (the first hit whose results are missing) and the extension problems requested from it on (the
+    // hit's own and, speculatively, those of the hits behind it): collected by the walks, written after the
+    // workgroup's allocation
+    uint32_t f_hno = 0;
     int f_bw = 0, f_xd = 0;
-    unsigned f_ord = 0, f_req = 0, f_ops = 0, f_cls[4] = {0, 0, 0, 0};
-    // allocation results, used by the request-writing walk
-    unsigned long long w_rec = 0, w_dpo = 0, w_q[4] = {0, 0, 0, 0};
-    unsigned w_n = 0;
+    Pend pend[TPR_MAX_PEND];
+    int n_pend = 0;
+    bool pend_over = false;
 
     ReadRecT<C> rec;
     rec.len = 0xFFFFFFFFu;
     rec.base_off = 0;
+    rec.n_hits = 0;
     if (active) rec = p.read_recs[idx];
-    const bool mine = active && rec.len <= p.max_read_len;
+    const bool mine = active && rec.len <= p.max_read_len && rec.n_hits < tp.max_hits;
     const uint8_t* rd = p.reads.bases + rec.base_off;
     L = mine ? (int)rec.len : 0;
-    auto rec_of = [&](unsigned ord) -> uint32_t {
-      unsigned cum = 0;
-      uint32_t r = 0;
-      for (int k = 0; k < TPR_MAX_ROUNDS; k++) {
-        const unsigned c = (k < (int)memo.n_rounds) ? memo.cnt[k] : 0u;
-        if (ord >= cum && ord < cum + c) r = memo.base[k] + (ord - cum);
-        cum += c;
+
+    // the read's hits in align_read's order: SMEMs as listed, occurrences by descending suffix-array rank
+    auto load_sm = [&](uint32_t si) -> SmemT<C> {
+      SmemT<C> sm;
+      if (si == 0) {
+        sm.lo = rec.lo0;
+        sm.hi = rec.hi0;
+        sm.qpos = rec.qpos0;
+        sm.len = rec.len0;
+      } else {
+        sm = p.smems[rec.smem_off + si];
       }
-      return r;
+      return sm;
     };
 
     // One walk over the extension problems of a hit, in the order the reference meets them.
-    //   mode 0  compute the hit's outcome; returns 1 when a DP result is missing
-    //   mode 1  count the requests        mode 2  write them
-    // Ordinals (the order of the memo): the unknown sides of the transcript targets in yield order (right, left), then
-    // those of the genome window -- which are requested only if the genome problem is not dead, known by then.
-    auto walk_hit = [&](const int mode, const SmemT<C>& sm, const C rr, const bool first_occ, const int bw, const int xd, const unsigned ord0,
-                        HitOut<S, C>& o) -> int {
+    //   compute  take the DP results from the memo and produce the hit's outcome; returns 1 when they are missing
+    //   else     (a hit behind the frontier, asked for speculatively) only collect the problems
+    // Problems whose results are missing are collected in pend[].  Order of the records of a hit: the unknown sides of
+    // the transcript targets in yield order (right, left), then those of the genome window -- which are requested only
+    // if the genome problem is not dead, known by then.
+    auto walk_hit = [&](const bool compute, const SmemT<C>& sm, const C rr, const bool first_occ, const int bw, const int xd, HitOut<S, C>& o) -> int {
+      const int mode = compute ? 0 : 1;
       const int q = sm.qpos, len = sm.len;
       const C hrc = first_occ ? rec.sa0 : ix.sa[rr - 1];
       const S hr = (S)hrc;
@@ -346,21 +424,17 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       // genome window (:212-215)
       const S seq_start = max((hr > (S)(L + bw)) ? hr - (S)(L + bw) : (S)0, (S)o.ref.start);
       const S seq_end = min(hr + (S)(len + L + bw), (S)o.ref.end - 1);
-      unsigned ord = ord0;
       bool need = false;
       o.calls = o.win = 0;
       o.cells = o.cols = 0;
-      o.m_req = o.m_ops = 0;
-      o.m_cls[0] = o.m_cls[1] = o.m_cls[2] = o.m_cls[3] = 0;
       o.why = 0;
-      // an extension that needs a DP: its result (mode 0), its count (mode 1), its record (mode 2)
+      // an extension that needs a DP: its result from the memo, or one more problem to ask for
       auto unknown_side = [&](Side& s, const uint8_t* x0, const uint8_t* y0, int dir, int xlen, long long ylen) {
-        const unsigned od = ord++;
         const int slots = min(2 * bw + 1, xlen + 1);
-        const unsigned cls = (unsigned)((slots + 63) / 64);
-        if (mode == 0) {
-          if (od < avail) {
-            const uint32_t ri = rec_of(od);
+        if (compute) {
+          const unsigned od = ord_r++;
+          if (round_ok && od < (unsigned)memo.cnt[k_round]) {
+            const uint32_t ri = memo.base[k_round] + od;
             const DpRec* d = tp.recs + ri;
             s.score = d->score;
             s.xend = d->xend;
@@ -369,38 +443,27 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
             s.rec = (int)ri;
             o.cells += d->cells;
             o.cols += d->cols;
-            if (d->done != 1) o.why = 7;  // cannot be: every record of an earlier round was computed
-          } else {
-            need = true;
+            // cannot be: every record of an earlier round was computed, for exactly this problem; and a hit's results
+            // are there as a whole or not at all
+            if (need || d->done != 1 || d->xlen != (uint16_t)xlen || d->ylen != (uint16_t)ylen || d->bw != (uint16_t)bw || d->dir != (int8_t)dir) {
+              o.why = 7;
+              atomicOr(p.fault, 2 | 128);  // (diagnosis)
+            }
+            return;
           }
-        } else if (mode == 1) {
-          o.m_req++;
-          o.m_ops += ((unsigned)xlen + (unsigned)ylen + 3u) & ~3u;
-          o.m_cls[cls - 1]++;
+          need = true;
+        }
+        if (n_pend < TPR_MAX_PEND) {
+          Pend& e = pend[n_pend++];
+          e.x0 = x0;
+          e.y0 = y0;
+          e.xlen = (uint16_t)xlen;
+          e.ylen = (uint16_t)ylen;
+          e.dir = (int8_t)dir;
+          e.cls = (uint8_t)((slots + 63) / 64);
+          e.pad_ = 0;
         } else {
-          DpRec d;
-          d.x0 = x0;
-          d.y0 = y0;
-          d.ops_off = w_dpo;
-          d.xlen = (uint16_t)xlen;
-          d.ylen = (uint16_t)ylen;
-          d.bw = (uint16_t)bw;
-          d.xd = (uint16_t)min(xd, 65535);
-          d.dir = (int8_t)dir;
-          d.cls = (uint8_t)cls;
-          d.pad_ = 0;
-          d.read = (uint32_t)idx;
-          d.score = 0;
-          d.xend = d.yend = d.nops = 0;
-          d.done = 0;
-          d.cells = d.cols = 0;
-          d.pad2_ = 0;
-          const uint32_t ri = (uint32_t)(w_rec + w_n);
-          tp.recs[ri] = d;
-          tp.q_list[(size_t)(cls - 1) * tp.q_stride + w_q[cls - 1]] = ri;
-          w_q[cls - 1]++;
-          w_dpo += ((unsigned)xlen + (unsigned)ylen + 3u) & ~3u;
-          w_n++;
+          pend_over = true;
         }
       };
       // the two sides of extend_left_right (src/aligner.rs:352-407) for a target spanning [lo_abs, hi_abs)
@@ -441,16 +504,27 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       o.gx.l = side_classify(gg.xl0, gg.yl0, -1, gg.xl, gg.yl, xd);
       const bool gx_known = o.gx.l.known && o.gx.r.known;
       const int gx_ub = o.gx.l.ub + len * MATCH_SCORE + o.gx.r.ub;
-      // exon_to_tx.find(seed) in yield order (:231-258)
+      // exon_to_tx.find(seed) in yield order (:231-258): by ascending pre-order rank.  A bin's entries are sorted by
+      // rank, a seed spans one bin or two: a merge of two sorted lists, skipping what does not overlap and the second
+      // copy of an interval listed in both bins.
       const uint32_t b0 = (uint32_t)(qs >> GRID_SHIFT), b1 = (uint32_t)((qe > qs ? qe - 1 : qs) >> GRID_SHIFT);
       const uint32_t e0 = ix.exon_grid_off[b0], e1 = ix.exon_grid_off[b1 + 1];
-      const uint32_t cnt = e1 - e0;
-      const ExonEntryT<C>* ent = ix.exon_grid + e0;
+      const uint32_t emid = (b1 == b0) ? e1 : ix.exon_grid_off[b0 + 1];
+      const ExonEntryT<C>* ent = ix.exon_grid;
       o.e0 = e0;
-      if (cnt > (uint32_t)TPR_MAX_ENT) {
+      if (e1 - e0 > (uint32_t)TPR_MAX_ENT || b1 > b0 + 1) {
         o.why = 2;
         return 2;
       }
+      uint32_t gi = e0, gj = emid;  // cursors of the two lists
+      auto grid_skip = [&](uint32_t& t, uint32_t end) {
+        while (t < end) {
+          const C es = ent[t].start, ee = ent[t].end;
+          const uint32_t home = max(b0, (uint32_t)(es >> GRID_SHIFT));
+          if (qs < ee && es < qe && (ent[t].rank & 0xffu) == (home & 0xffu)) break;
+          t++;
+        }
+      };
       o.have_best = false;
       o.best_tx = o.best_ent = 0;
       int known_best = -1;  // best score among the targets known in closed form
@@ -459,25 +533,17 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       int alias_pos = 0, best_pos = 0, pos = 0;
       uint32_t alias_tx = 0, alias_ent = 0;
       int alias_tr = 0;
-      int last = -1;
       bool stop = false;
       while (!stop) {
-        int best_rank = 0x0fffffff;
-        uint32_t ei = 0;
-        for (uint32_t t = 0; t < cnt; t++) {
-          const C es = ent[t].start, ee = ent[t].end;
-          const uint32_t rk = ent[t].rank;
-          const bool overlap = qs < ee && es < qe;
-          const uint32_t home = max(b0, (uint32_t)(es >> GRID_SHIFT));
-          const bool primary = (rk & 0xffu) == (home & 0xffu);
-          const int r2 = (overlap && primary) ? (int)(rk >> 8) : -1;
-          if (r2 > last && r2 < best_rank) {
-            best_rank = r2;
-            ei = t;
-          }
-        }
-        if (best_rank == 0x0fffffff) break;
-        last = best_rank;
+        grid_skip(gi, emid);
+        grid_skip(gj, e1);
+        uint32_t ei;
+        if (gi < emid && (gj >= e1 || ent[gi].rank <= ent[gj].rank))
+          ei = gi++;
+        else if (gj < e1)
+          ei = gj++;
+        else
+          break;
         const ExonEntryT<C> ge = ent[ei];
         if (!(ge.prev_end <= qs)) {  // lift_mem_to_tx's general case (a seed across a short intron)
           o.why = 3;
@@ -509,8 +575,9 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         const LrGeom tg = lr_geom(seq, (S)0, (S)tlen, (S)tr_, t_q, t_len);
         // Same seed on the read and the same y bytes as the genome problem (the hit lies inside one exon that covers
         // both windows): the two extend() calls have the genome calls' inputs, hence its results.
+        // (With a genome problem known in closed form the target's sides are simply classified: same bytes, same answer.)
         bool same = false;
-        if (t_q == q && t_len == len && tg.yr == gg.yr && tg.yl == gg.yl) {
+        if (!gx_known && t_q == q && t_len == len && tg.yr == gg.yr && tg.yl == gg.yl) {
           same = (gg.xr == 0 || gg.yr <= 0 || match_fwd(tg.yr0, gg.yr0, (int)gg.yr) == (int)gg.yr) &&
                  (gg.xl == 0 || gg.yl <= 0 || match_fwd(tg.yl0 + 1 - (int)gg.yl, gg.yl0 + 1 - (int)gg.yl, (int)gg.yl) == (int)gg.yl);
         }
@@ -519,16 +586,14 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         if (same) {
           pth.l = o.gx.l;
           pth.r = o.gx.r;
-          p_known = gx_known;
-          if (!gx_known) {
-            p_scored = false;
-            if (!alias) {
-              alias = true;
-              alias_pos = pos;
-              alias_tx = ge.value;
-              alias_ent = ei;
-              alias_tr = tr_;
-            }
+          p_known = false;
+          p_scored = false;
+          if (!alias) {
+            alias = true;
+            alias_pos = pos;
+            alias_tx = ge.value;
+            alias_ent = ei - e0;
+            alias_tr = tr_;
           }
         } else {
           pth.r = side_classify(tg.xr0, tg.yr0, 1, tg.xr, tg.yr, xd);
@@ -546,7 +611,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
           if (!o.have_best || pth.score > o.best.score) {  // strictly better (:249)
             o.have_best = true;
             o.best_tx = ge.value;
-            o.best_ent = ei;
+            o.best_ent = ei - e0;
             o.best = pth;
             best_pos = pos;
           }
@@ -556,13 +621,12 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         pos++;
       }
       // ---- the genome problem: dead when a target known in closed form reaches its upper bound and no target takes
-      // its result (it is not computed then and takes no ordinals); else its unknown sides are the hit's last requests ----
+      // its result (it is not computed then and takes no records); else its unknown sides are the hit's last requests ----
       o.gx_dead = !gx_known && !alias && known_best >= gx_ub;
       if (!o.gx_dead) {
         if (!o.gx.r.known) unknown_side(o.gx.r, gg.xr0, gg.yr0, 1, gg.xr, gg.yr);
         if (!o.gx.l.known) unknown_side(o.gx.l, gg.xl0, gg.yl0, -1, gg.xl, gg.yl);
       }
-      o.ord_end = ord;
       if (o.why) return 2;
       if (mode != 0) return 0;
       if (need) return 1;
@@ -581,19 +645,13 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       }
       return 0;
     };
-
     if (mine) {
       cand0 = rec.cand_off;
-      if (rec.n_hits >= HEAVY_HITS) {
-        why = 7;  // on the lists of plan_kernel already (heavy / team)
-      } else if (cand0 + rec.n_hits > p.cand_cap) {
+      if (cand0 + rec.n_hits > p.cand_cap) {
         bail = true;  // the wave-per-read kernel raises the pool fault
         why = 7;
       } else {
-        if (tp.round > 0) {
-          memo = tp.memos[idx];
-          for (int k = 0; k < TPR_MAX_ROUNDS; k++) avail += (k < (int)memo.n_rounds) ? memo.cnt[k] : 0u;
-        }
+        if (tp.round > 0) memo = tp.memos[idx];  // (round 0: no rounds yet)
         // thresholds, src/aligner.rs:130-138 (binary32 product, truncation toward zero)
         const float prod = p.opts.min_aln_score_percent * (float)L;
         const int ms_pct = (prod != prod) ? 0 : (prod >= 2147483648.0f ? 2147483647 : (prod <= -2147483648.0f ? (-2147483647 - 1) : (int)prod));
@@ -607,62 +665,65 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
           bail = true;
           why = 1;
         }
-        uint32_t n_acc = 0;
-        unsigned ord = 0;  // ordinal of the next extension that needs a DP
+        uint32_t n_acc = 0, hno = 0;
         const uint32_t n_sm = rec.smem_cnt;
         for (uint32_t si = 0; !bail && !sleep && si < n_sm; si++) {
-          SmemT<C> sm;
-          if (si == 0) {
-            sm.lo = rec.lo0;
-            sm.hi = rec.hi0;
-            sm.qpos = rec.qpos0;
-            sm.len = rec.len0;
-          } else {
-            sm = p.smems[rec.smem_off + si];
-          }
-          for (C rr = sm.hi; !bail && !sleep && rr > sm.lo; rr--) {
+          const SmemT<C> sm = load_sm(si);
+          for (C rr = sm.hi; !bail && !sleep && rr > sm.lo; rr--, hno++) {
             // ================= align_seed_hit (src/aligner.rs:198-314) =================
             const int bw = band_width, xd = x_drop;
-            HitOut<S, C> h;
-            int st = 0, mode = 0;
-            for (;;) {
-              st = walk_hit(mode, sm, rr, si == 0 && rr == sm.hi, bw, xd, ord, h);
-              if (mode == 0 && st == 1) {
-                // results are missing: this hit is the round's frontier (a hit is requested as a whole, so none of
-                // its results can be there); a second walk counts its requests
-                if (avail != ord || memo.n_rounds >= TPR_MAX_ROUNDS || tp.last_round != 0) {
-                  st = 2;
-                  h.why = avail != ord ? 7 : 6;
-                  break;
-                }
-                mode = 1;
-                continue;
-              }
-              break;
+            // a round of the memo that was requested from this hit on: its records are for the state in force now
+            while (k_round + 1 < (int)memo.n_rounds && memo.first_hit[k_round + 1] == (uint16_t)hno) {
+              k_round++;
+              ord_r = 0;
+              round_ok = true;
             }
+            HitOut<S, C> h;
+            const int st = walk_hit(true, sm, rr, si == 0 && rr == sm.hi, bw, xd, h);
             if (st == 2) {
               bail = true;
               why = h.why;
               break;
             }
-            if (mode == 1) {
-              if (h.m_req > 255u || h.m_req == 0u) {
+            if (st == 1) {
+              // results are missing: this hit is the round's frontier; its problems are in pend[]
+              if (memo.n_rounds >= TPR_MAX_ROUNDS || tp.last_round != 0 || pend_over || n_pend == 0) {
                 bail = true;
                 why = 6;
                 break;
               }
+              // While no candidate has been accepted the state is the wide initial one and the first acceptance
+              // will narrow it: ask for few hits (1, 2, 4, ...).  After that it rarely moves: all the remaining hits,
+              // as far as pend[] holds their problems.  A hit behind the frontier that this path cannot take ends the
+              // batch; if the replay gets there it asks again, or leaves the read to the wave-per-read kernel.
+              uint32_t left = n_acc > 0 ? 0xFFFFFFFFu : (1u << min((int)memo.n_rounds, 5));
+              uint32_t si2 = si;
+              SmemT<C> sm2 = sm;
+              C rr2 = rr;
+              while (--left) {
+                rr2--;
+                while (rr2 <= sm2.lo) {  // next SMEM with occurrences
+                  si2++;
+                  if (si2 >= n_sm) break;
+                  sm2 = load_sm(si2);
+                  rr2 = sm2.hi;
+                }
+                if (si2 >= n_sm) break;
+                const int mark = n_pend;
+                HitOut<S, C> h2;
+                const int st2 = walk_hit(false, sm2, rr2, false, bw, xd, h2);
+                if (st2 == 2 || pend_over) {
+                  n_pend = mark;
+                  pend_over = false;
+                  break;
+                }
+              }
               sleep = true;
-              f_si = si;
-              f_rr = rr;
               f_bw = bw;
               f_xd = xd;
-              f_ord = ord;
-              f_req = h.m_req;
-              f_ops = h.m_ops;
-              for (int c2 = 0; c2 < 4; c2++) f_cls[c2] = h.m_cls[c2];
+              f_hno = hno;
               break;
             }
-            ord = h.ord_end;
             calls += h.calls;
             winbytes += h.win;
             dp_cells += h.cells;
@@ -844,6 +905,8 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
             band_width = min(band_width, lim);
             x_drop = min(x_drop, lim);
             max_aln_score = max(max_aln_score, sc);
+            // requests behind this hit were made for the band and X-drop in force when it was reached
+            if (band_width != bw || x_drop != xd) round_ok = false;
           }
         }
         if (!bail && !sleep) {
@@ -910,13 +973,13 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
           }
         }
       }
-    } else if (active) {
-      why = 7;  // not this class: listed by plan_kernel
     }
     if (bail) sleep = false;
 
     // ---- workgroup allocations: op bytes of finished reads; records, DP op room, queue and list slots of sleeping /
     // bailing reads.  One exclusive scan per quantity over the workgroup, one atomic per quantity and workgroup. ----
+    // a read left to the wave-per-read kernels goes to the workgroup-per-read (team) kernel if it has the hits for it
+    const bool bail_team = bail && tp.team != nullptr && rec.n_hits >= TEAM_MIN_HITS && rec.n_hits <= TEAM_MAX_HITS;
     unsigned want[NALLOC];
     for (int a2 = 0; a2 < NALLOC; a2++) want[a2] = 0;
     if (done) {
@@ -929,12 +992,14 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       }
     }
     if (sleep) {
-      want[A_REC] = f_req;
-      want[A_DPO] = f_ops;
+      want[A_REC] = (unsigned)n_pend;
       want[A_ACT] = 1;
-      for (int c2 = 0; c2 < 4; c2++) want[A_Q0 + c2] = f_cls[c2];
+      for (int t = 0; t < n_pend; t++) {
+        want[A_DPO] += ((unsigned)pend[t].xlen + (unsigned)pend[t].ylen + 3u) & ~3u;
+        want[A_Q0 + pend[t].cls - 1]++;
+      }
     }
-    if (bail) want[A_BAIL] = 1;
+    if (bail) want[bail_team ? A_BAILT : A_BAIL] = 1;
     unsigned incl[NALLOC];
     for (int a2 = 0; a2 < NALLOC; a2++) {
       unsigned v = want[a2];
@@ -954,8 +1019,9 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
                                 : a2 == A_DPO ? tp.dp_ops_cursor
                                 : a2 == A_ACT ? tp.n_act_out
                                 : a2 == A_BAIL ? tp.bail_count
-                                               : &tp.q_cur[a2 - A_Q0];
-      s_base[a2] = tot ? atomicAdd(cur, (unsigned long long)tot) : 0ull;
+                                : a2 == A_BAILT ? tp.team_count
+                                                : &tp.q_cur[a2 - A_Q0];
+      s_base[a2] = (tot && cur) ? atomicAdd(cur, (unsigned long long)tot) : 0ull;
     }
     __syncthreads();
     unsigned long long mine_at[NALLOC], blk_end[NALLOC];
@@ -981,31 +1047,57 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       const unsigned long long slot = atomicAdd(tp.bail_count, 1ull);  // (a late bail has no slot of this pass's allocation)
       tp.bail[slot] = idx;
       why = 6;
-      // its slot in the next round's list stays: mark it empty
-      tp.act_out[mine_at[A_ACT]] = 0xFFFFFFFFu;
+      tp.act_out[mine_at[A_ACT]] = 0xFFFFFFFFu;  // its slot in the next round's list stays: marked empty
+      {  // ... and so do its slots in the DP queues (as far as they lie inside the lists)
+        unsigned long long qs4[4] = {mine_at[A_Q0], mine_at[A_Q0 + 1], mine_at[A_Q0 + 2], mine_at[A_Q0 + 3]};
+        for (int t = 0; t < n_pend; t++) {
+          const int c2 = pend[t].cls - 1;
+          if (qs4[c2] < tp.q_stride) tp.q_list[(size_t)c2 * tp.q_stride + qs4[c2]] = 0xFFFFFFFFu;
+          qs4[c2]++;
+        }
+      }
     }
-    if (bail) tp.bail[mine_at[A_BAIL]] = idx;
+    if (bail) {
+      if (bail_team)
+        tp.team[mine_at[A_BAILT]] = idx;
+      else
+        tp.bail[mine_at[A_BAIL]] = idx;
+    }
     if (sleep) {
       tp.act_out[mine_at[A_ACT]] = (uint32_t)idx;
-      // ---- write the frontier hit's requests: the same walk once more, now with the allocation ----
-      SmemT<C> sm;
-      if (f_si == 0) {
-        sm.lo = rec.lo0;
-        sm.hi = rec.hi0;
-        sm.qpos = rec.qpos0;
-        sm.len = rec.len0;
-      } else {
-        sm = p.smems[rec.smem_off + f_si];
+      // ---- the collected problems become records, queued by band class ----
+      unsigned long long dpo = mine_at[A_DPO], qs4[4] = {mine_at[A_Q0], mine_at[A_Q0 + 1], mine_at[A_Q0 + 2], mine_at[A_Q0 + 3]};
+      const unsigned long long w_rec = mine_at[A_REC];
+      const unsigned w_n = (unsigned)n_pend;
+      for (int t = 0; t < n_pend; t++) {
+        const Pend& e = pend[t];
+        DpRec d;
+        d.x0 = e.x0;
+        d.y0 = e.y0;
+        d.ops_off = dpo;
+        d.xlen = e.xlen;
+        d.ylen = e.ylen;
+        d.bw = (uint16_t)f_bw;
+        d.xd = (uint16_t)min(f_xd, 65535);
+        d.dir = e.dir;
+        d.cls = e.cls;
+        d.pad_ = 0;
+        d.read = (uint32_t)idx;
+        d.score = 0;
+        d.xend = d.yend = d.nops = 0;
+        d.done = 0;
+        d.cells = d.cols = 0;
+        d.pad2_ = 0;
+        const uint32_t ri = (uint32_t)(w_rec + (unsigned)t);
+        tp.recs[ri] = d;
+        tp.q_list[(size_t)(e.cls - 1) * tp.q_stride + qs4[e.cls - 1]] = ri;
+        qs4[e.cls - 1]++;
+        dpo += ((unsigned)e.xlen + (unsigned)e.ylen + 3u) & ~3u;
       }
-      w_rec = mine_at[A_REC];
-      w_dpo = mine_at[A_DPO];
-      for (int c2 = 0; c2 < 4; c2++) w_q[c2] = mine_at[A_Q0 + c2];
-      w_n = 0;
-      HitOut<S, C> h;
-      (void)walk_hit(2, sm, f_rr, f_si == 0 && f_rr == sm.hi, f_bw, f_xd, f_ord, h);
       ReadMemo m2 = memo;
       m2.base[memo.n_rounds] = (uint32_t)w_rec;
-      m2.cnt[memo.n_rounds] = (uint8_t)w_n;
+      m2.cnt[memo.n_rounds] = (uint16_t)w_n;
+      m2.first_hit[memo.n_rounds] = (uint16_t)f_hno;
       m2.n_rounds = (uint8_t)(memo.n_rounds + 1);
       for (int k = 0; k < 7; k++) m2.pad_[k] = 0;
       tp.memos[idx] = m2;
@@ -1103,10 +1195,10 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       add(THM_CNT_OP_BYTES, done ? opb : 0ull);
       add(THM_CNT_WINDOW_BYTES, done ? (unsigned long long)winbytes : 0ull);
       if (tp.stats) {
-        const unsigned long long mk = __ballot(mine && !done && !sleep && rec.n_hits < HEAVY_HITS);
+        const unsigned long long mk = __ballot(mine && !done && !sleep);
         if (lane == 0 && mk) atomicAdd(&s_stats[0], (unsigned)__popcll(mk));
         for (int w = 1; w < 8; w++) {
-          const unsigned long long m2 = __ballot(mine && !done && !sleep && rec.n_hits < HEAVY_HITS && why == w);
+          const unsigned long long m2 = __ballot(mine && !done && !sleep && why == w);
           if (lane == 0 && m2) atomicAdd(&s_stats[w], (unsigned)__popcll(m2));
         }
       }
@@ -1121,41 +1213,76 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// DP kernel: one request per wavefront.  The requests of band class CPL queued since the last round: q_list[q_done .. q_cur).
+// The reads the control kernel takes (fast class, fewer than max_hits hits), by descending hit count: the threads of a
+// wavefront walk the hits of 64 reads in lockstep, so a wavefront takes as long as its read with the most hits --
+// reads of like hit counts belong together, and the long ones go first.  Two launches: phase 0 counts the reads per
+// hit count, phase 1 places them (order within a hit count: as the workgroups come).
+// bins: [0, 64) counts, [64, 128) cursors.
+// ---------------------------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256) void tpr_order_kernel(const ReadRecT<C>* recs, uint64_t n, uint32_t max_len, uint32_t max_hits, unsigned long long* bins,
+                                                        uint32_t* out, unsigned long long* n_out, const int* fault_seed, int phase) {
+  __shared__ unsigned h[64], base[64];
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  int b = -1;
+  if (r < n && *fault_seed == 0) {
+    const uint32_t len = recs[r].len, nh = recs[r].n_hits;
+    if (len <= max_len && nh < max_hits) b = (int)min(nh, 63u);
+  }
+  unsigned pos = 0;
+  if (b >= 0) pos = atomicAdd(&h[b], 1u);
+  __syncthreads();
+  if (phase == 0) {
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+    return;
+  }
+  if (threadIdx.x < 64) {
+    // reads with more hits come first: the bin's start is the number of reads with more hits
+    unsigned long long before = 0, total = 0;
+    for (int k = 0; k < 64; k++) {
+      const unsigned long long c = bins[k];
+      if (k > (int)threadIdx.x) before += c;
+      total += c;
+    }
+    base[threadIdx.x] = (unsigned)(before + (h[threadIdx.x] ? atomicAdd(&bins[64 + threadIdx.x], (unsigned long long)h[threadIdx.x]) : 0ull));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = total;
+  }
+  __syncthreads();
+  if (b >= 0) out[base[b] + pos] = (uint32_t)r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DP kernel: one request per wavefront.  The requests queued since the last round, band class by band class:
+// q_list[c][q_done[c] .. q_cur[c]).  A wave's first chunk of a class is its own by position (no atomic: a launch
+// that finds nothing to do costs nothing), further chunks come from the class's work counter.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CPL>
-__global__ __launch_bounds__(256) void extend_dp_kernel(DpParams p) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void dp_class(const DpParams& p, uint8_t* xs, uint8_t* ys, unsigned long long* trace_lds, uint8_t* opsb, uint32_t ops_cap,
+                                         unsigned wave_global, unsigned n_waves, int& fault) {
+  // the trace of a one-cell-per-lane problem (16 bytes per column) is in LDS; the rare wider ones keep theirs in a
+  // wave-private slice of global memory, so that the LDS footprint -- hence the waves per CU -- is set by the common case
+  unsigned long long* trace = CPL == 1 ? trace_lds : p.trace_scratch + (size_t)wave_global * p.trace_per_wave;
   const int lane = lane_id();
-  const int wave = bcast_first((int)(threadIdx.x >> 6));
-  const uint32_t tr_bytes = (p.y_cap + 1) * CPL * 16;
-  const uint32_t ops_cap = p.x_cap + p.y_cap + 16;
-  const uint32_t per_wave = p.x_cap + p.y_cap + tr_bytes + ops_cap;
-  uint8_t* xs = smem + (size_t)wave * per_wave;
-  uint8_t* ys = xs + p.x_cap;
-  unsigned long long* trace = (unsigned long long*)(ys + p.y_cap);
-  uint8_t* opsb = (uint8_t*)trace + tr_bytes;
-  const unsigned long long q0 = p.q_done[CPL - 1], q1 = p.q_cur[CPL - 1];
+  // (the cursor may have run past the list when the request pools were exhausted: those reads went to the wave-per-read
+  // kernel and their slots, as far as they exist, hold 0xFFFFFFFF)
+  const unsigned long long q0 = min(p.q_done[CPL - 1], (unsigned long long)p.q_stride), q1 = min(p.q_cur[CPL - 1], (unsigned long long)p.q_stride);
+  if (q0 >= q1) return;
   const uint32_t* list = p.q_list + (size_t)(CPL - 1) * p.q_stride;
-  int fault = 0;
-  constexpr unsigned QCHUNK = 4;  // requests per queue atomic
-  unsigned long long q_next = 0, q_end = 0;
-  for (;;) {
-    if (q_next == q_end) {
-      unsigned g = 0;
-      if (lane == 0) g = atomicAdd(p.work, QCHUNK);
-      g = (unsigned)bcast_first((int)g);
-      if (q0 + g >= q1) break;
-      q_next = q0 + g;
-      q_end = min(q_next + QCHUNK, q1);
-    }
-    const uint32_t ri = list[q_next++];
+  // Requests are handed out by position, wave w takes w, w + n_waves, ...: a request is one extension of a few dozen
+  // columns, a wave gets dozens of them, so the shares even out -- and there is no work counter (one hot word serves
+  // about 88 M returning atomics per second: 175 000 chunks of two took 2 ms, whatever the occupancy).
+  (void)fault;
+  for (unsigned long long q_next = q0 + wave_global; q_next < q1; q_next += n_waves) {
+    const uint32_t ri = list[q_next];
+    if (ri == 0xFFFFFFFFu) continue;
     const DpRec rq = p.recs[ri];
     const int xlen = (int)bcast_first((int)rq.xlen), ylen = (int)bcast_first((int)rq.ylen);
     const int bw = (int)bcast_first((int)rq.bw), xd = (int)bcast_first((int)rq.xd);
     const int dir = (int)bcast_first((int)rq.dir);
     if ((uint32_t)xlen + 64u > p.x_cap || (uint32_t)ylen + 64u > p.y_cap || min(2 * bw + 1, xlen + 1) > 64 * CPL) {
-      fault = 1;
+      fault |= 1;
       continue;
     }
 #pragma unroll 1
@@ -1164,11 +1291,14 @@ __global__ __launch_bounds__(256) void extend_dp_kernel(DpParams p) {
     for (int t = lane; t < ylen; t += 64) ys[t] = rq.y0[t * dir];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     SwgResult r = swg_extend_wave<CPL>(xs, 1, xlen, ys, 1, ylen, bw, xd, trace);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (CPL == 1)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    else
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // lane 0's trace stores must be visible to the loads of all lanes
     int nops = swg_traceback_wave<CPL>(trace, r.xend, r.yend, bw, opsb, 1, (int)ops_cap);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (nops < 0 || nops > xlen + ylen) {
-      fault = 1;
+      fault |= nops < 0 ? 2 : 4;
       nops = 0;
     }
     uint8_t* out = p.dp_ops + rq.ops_off;
@@ -1186,17 +1316,37 @@ __global__ __launch_bounds__(256) void extend_dp_kernel(DpParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
-  if (lane == 0) {
-    if (fault) atomicOr(p.fault, 2);  // FAULT_INTERNAL (kernels_extend.hip)
-  }
+}
+
+// CPLMAX: the widest band class of the run (the LDS trace is sized for it)
+template <int CPLMAX>
+__global__ __launch_bounds__(256) void extend_dp_kernel(DpParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = bcast_first((int)(threadIdx.x >> 6));
+  const unsigned wave_global = blockIdx.x * 4u + (unsigned)wave, n_waves = gridDim.x * 4u;
+  const uint32_t tr_bytes = (p.y_cap + 1) * 16;
+  const uint32_t ops_cap = p.x_cap + p.y_cap + 16;
+  const uint32_t per_wave = p.x_cap + p.y_cap + tr_bytes + ops_cap;
+  uint8_t* xs = smem + (size_t)wave * per_wave;
+  uint8_t* ys = xs + p.x_cap;
+  unsigned long long* trace = (unsigned long long*)(ys + p.y_cap);
+  uint8_t* opsb = (uint8_t*)trace + tr_bytes;
+  int fault = 0;
+  dp_class<1>(p, xs, ys, trace, opsb, ops_cap, wave_global, n_waves, fault);
+  if constexpr (CPLMAX >= 2) dp_class<2>(p, xs, ys, trace, opsb, ops_cap, wave_global, n_waves, fault);
+  if constexpr (CPLMAX >= 3) dp_class<3>(p, xs, ys, trace, opsb, ops_cap, wave_global, n_waves, fault);
+  if constexpr (CPLMAX >= 4) dp_class<4>(p, xs, ys, trace, opsb, ops_cap, wave_global, n_waves, fault);
+  if (lane_id() == 0 && fault) atomicOr(p.fault, 2 | (fault << 4));  // FAULT_INTERNAL (kernels_extend.hip) + which check (diagnosis)
 }
 
 }  // namespace dev
 
-size_t extend_dp_lds_bytes(uint32_t x_cap, uint32_t y_cap, int cpl) {
-  const size_t tr = (size_t)(y_cap + 1) * cpl * 16;
+size_t extend_dp_lds_bytes(uint32_t x_cap, uint32_t y_cap) {
+  const size_t tr = (size_t)(y_cap + 1) * 16;
   return 4 * ((size_t)x_cap + y_cap + tr + x_cap + y_cap + 16);
 }
+// global trace scratch of one wave (problems of more than 64 band slots), in bytes
+size_t extend_dp_trace_bytes(uint32_t y_cap, int cpl_max) { return cpl_max > 1 ? (size_t)(y_cap + 2) * (size_t)cpl_max * 16 : 0; }
 
 template <class C>
 static hipError_t launch_extend_ctl_t(const ExtendParamsT<C>& p, const TprParamsT<C>& tp, int n_blocks, hipStream_t s) {
@@ -1211,8 +1361,26 @@ hipError_t launch_extend_ctl(const ExtendParamsT<uint64_t>& p, const TprParamsT<
   return launch_extend_ctl_t(p, tp, n_blocks, s);
 }
 
-hipError_t launch_extend_dp(const DpParams& p, int cpl, int n_blocks, hipStream_t s) {
-  const size_t lds = extend_dp_lds_bytes(p.x_cap, p.y_cap, cpl);
+template <class C>
+static hipError_t launch_tpr_order_t(const ReadRecT<C>* recs, uint64_t n, uint32_t max_len, uint32_t max_hits, unsigned long long* bins, uint32_t* out,
+                                     unsigned long long* n_out, const int* fault_seed, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(dev::tpr_order_kernel<C>, dim3(blocks), dim3(256), 0, s, recs, n, max_len, max_hits, bins, out, n_out, fault_seed, 0);
+  hipLaunchKernelGGL(dev::tpr_order_kernel<C>, dim3(blocks), dim3(256), 0, s, recs, n, max_len, max_hits, bins, out, n_out, fault_seed, 1);
+  return hipGetLastError();
+}
+hipError_t launch_tpr_order(const ReadRecT<uint32_t>* recs, uint64_t n, uint32_t max_len, uint32_t max_hits, unsigned long long* bins, uint32_t* out,
+                            unsigned long long* n_out, const int* fault_seed, hipStream_t s) {
+  return launch_tpr_order_t(recs, n, max_len, max_hits, bins, out, n_out, fault_seed, s);
+}
+hipError_t launch_tpr_order(const ReadRecT<uint64_t>* recs, uint64_t n, uint32_t max_len, uint32_t max_hits, unsigned long long* bins, uint32_t* out,
+                            unsigned long long* n_out, const int* fault_seed, hipStream_t s) {
+  return launch_tpr_order_t(recs, n, max_len, max_hits, bins, out, n_out, fault_seed, s);
+}
+
+hipError_t launch_extend_dp(const DpParams& p, int cpl_max, int n_blocks, hipStream_t s) {
+  const size_t lds = extend_dp_lds_bytes(p.x_cap, p.y_cap);
   auto go = [&](auto kern) -> hipError_t {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1221,7 +1389,7 @@ hipError_t launch_extend_dp(const DpParams& p, int cpl, int n_blocks, hipStream_
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), lds, s, p);
     return hipGetLastError();
   };
-  switch (cpl) {
+  switch (cpl_max) {
     case 1: return go(dev::extend_dp_kernel<1>);
     case 2: return go(dev::extend_dp_kernel<2>);
     case 3: return go(dev::extend_dp_kernel<3>);

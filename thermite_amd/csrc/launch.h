@@ -104,6 +104,8 @@ struct PlanParams {
   uint32_t team_ok;
   const uint64_t* total_hits;  // hits of the whole batch (the last element of the scan of read_hits)
   uint32_t team_div;           // team threshold = clamp(total_hits / team_div, TEAM_MIN_HITS, TEAM_HITS); see TEAM_HITS
+  uint32_t tpr_max_hits;       // > 0: the problem-parallel path takes the reads with fewer hits (kernels_tpr.hip): the heavy
+                               // list starts there and so does the team list
   unsigned long long* counts;  // work_counts of the seed stage
   int32_t* read_status;
   uint32_t* read_n_alns;       // zeroed for unsupported reads
@@ -276,14 +278,20 @@ struct DpRec {
 };
 static_assert(sizeof(DpRec) == 64, "DpRec layout");
 constexpr int TPR_MAX_ROUNDS = 8;  // rounds of requests one read may take (then: the wave-per-read kernel)
-// the records of a read, by round: ordinal o of the read's replay is record base[k] + (o - cnt[0] - .. - cnt[k-1])
+// Reads with this many seed hits and more stay with the workgroup-per-read / wave-per-read kernels: the control kernel
+// replays a read's hits in one thread, and a thread with thousands of hits would be the tail of its launch.
+constexpr unsigned TPR_MAX_HITS = 8;
+// The records of a read, by round: round k asked for the extension problems of the hits from first_hit[k] on (one
+// hit, or all the remaining ones), in the order the replay meets them, under the band and X-drop in force there:
+// records base[k] .. base[k] + cnt[k].
 struct ReadMemo {
   uint32_t base[TPR_MAX_ROUNDS];
-  uint8_t cnt[TPR_MAX_ROUNDS];
+  uint16_t cnt[TPR_MAX_ROUNDS];
+  uint16_t first_hit[TPR_MAX_ROUNDS];
   uint8_t n_rounds;
   uint8_t pad_[7];
 };
-static_assert(sizeof(ReadMemo) == 48, "ReadMemo layout");
+static_assert(sizeof(ReadMemo) == 72, "ReadMemo layout");
 template <class C>
 struct TprParamsT {
   ReadRecT<C>* recs_rw;   // = ExtendParamsT::read_recs, writable: a finished read gets len = 0xFFFFFFFF (skipped by every later kernel)
@@ -303,6 +311,9 @@ struct TprParamsT {
   unsigned long long* n_act_out;
   unsigned long long* bail;    // reads left to the wave-per-read kernel: appended to its list (ExtendParamsT::heavy)
   unsigned long long* bail_count;
+  unsigned long long* team;    // ... or, with TEAM_MIN_HITS hits and more, to the workgroup-per-read kernel's (null: none runs)
+  unsigned long long* team_count;
+  uint32_t max_hits;           // reads with this many hits and more are not this path's (TPR_MAX_HITS)
   uint32_t round;
   uint32_t last_round;         // 1: no DP launch follows; a read that still needs results goes to the wave-per-read kernel
   unsigned long long* stats;   // 8 words (may be null): [0] reads left to the wave-per-read kernel, [1..7] why
@@ -314,18 +325,27 @@ struct DpParams {
   uint64_t q_stride;
   const unsigned long long* q_cur;   // [4]
   const unsigned long long* q_done;  // [4] ends of the lists as of the previous round
-  unsigned int* work;                // work counter of this launch (zeroed before the run)
+  unsigned int* work;                // work counters of this launch, one per band class, 64 bytes apart (zeroed before the run)
   int* fault;
   uint32_t x_cap, y_cap;             // per-wave LDS bytes for x and y (multiples of 16, 64 bytes of slack each)
+  unsigned long long* trace_scratch; // problems of more than 64 band slots: [waves of the launch][trace_per_wave] u64
+  uint64_t trace_per_wave;
 };
-size_t extend_dp_lds_bytes(uint32_t x_cap, uint32_t y_cap, int cpl);  // per workgroup (4 waves)
+size_t extend_dp_lds_bytes(uint32_t x_cap, uint32_t y_cap);  // per workgroup (4 waves)
+size_t extend_dp_trace_bytes(uint32_t y_cap, int cpl_max);   // per wave
 hipError_t launch_extend_ctl(const ExtendParamsT<uint32_t>& p, const TprParamsT<uint32_t>& tp, int n_blocks, hipStream_t s);
 hipError_t launch_extend_ctl(const ExtendParamsT<uint64_t>& p, const TprParamsT<uint64_t>& tp, int n_blocks, hipStream_t s);
-hipError_t launch_extend_dp(const DpParams& p, int cpl, int n_blocks, hipStream_t s);
+hipError_t launch_extend_dp(const DpParams& p, int cpl_max, int n_blocks, hipStream_t s);  // all band classes up to cpl_max in one launch
+// the reads of the control kernel (fast class, fewer than max_hits hits) by descending hit count -> out[0 .. *n_out)
+hipError_t launch_tpr_order(const ReadRecT<uint32_t>* recs, uint64_t n, uint32_t max_len, uint32_t max_hits, unsigned long long* bins, uint32_t* out,
+                            unsigned long long* n_out, const int* fault_seed, hipStream_t s);
+hipError_t launch_tpr_order(const ReadRecT<uint64_t>* recs, uint64_t n, uint32_t max_len, uint32_t max_hits, unsigned long long* bins, uint32_t* out,
+                            unsigned long long* n_out, const int* fault_seed, hipStream_t s);
 constexpr int TPR_CTL_BLOCKS_PER_CU = 4, TPR_DP_BLOCKS_PER_CU = 8;
 // layout of the small control block of a run (u64 words; zeroed before the run)
-enum { TPRC_REC_CUR = 0, TPRC_DPO_CUR = 1, TPRC_Q_CUR = 2, TPRC_Q_DONE = 6, TPRC_N_ACT = 10 /* [TPR_MAX_ROUNDS + 2] */, TPRC_STATS = 24 /* [8] */,
-       TPRC_WORK_BYTES = 512 /* u32 work counters, 64 bytes apart: [round][class] */ };
+enum { TPRC_REC_CUR = 0, TPRC_DPO_CUR = 1, TPRC_Q_CUR = 2, TPRC_Q_DONE = 6, TPRC_N_ACT = 10 /* [TPR_MAX_ROUNDS + 2] */, TPRC_STATS = 24 /* [8] */, TPRC_BAIL_CNT = 23,
+       TPRC_BINS = 32 /* [128]: reads per hit count, cursors (tpr_order_kernel) */,
+       TPRC_WORK_BYTES = 2048 /* u32 work counters, 64 bytes apart: [round][class] */ };
 constexpr size_t TPRC_BYTES = TPRC_WORK_BYTES + (size_t)(TPR_MAX_ROUNDS + 1) * 4 * 64;
 
 struct CompactParams {

@@ -274,8 +274,13 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   // read | DP kernel, wave per request]; what it cannot take goes on the wave-per-read kernel's list ----
   const bool tpr = a->use_tpr && n > 0 && cpl <= 4;
   const int ctl_blocks = tpr ? (int)std::min<uint64_t>((n + 255) / 256, (uint64_t)a->n_cu * TPR_CTL_BLOCKS_PER_CU) : 0;
-  const int dp_blocks = tpr ? a->n_cu * TPR_DP_BLOCKS_PER_CU : 0;
-  const uint64_t tpr_rows = (uint64_t)ctl_blocks;
+  // DP workgroups that fit the machine at once (LDS: x, y, trace and op buffer of four waves)
+  const uint32_t dp_x_cap = (cls.fast_len + 64u + 15u) & ~15u, dp_y_cap = (cls.fast_len + cls.fast_bw + 2u + 64u + 15u) & ~15u;
+  const int dp_per_cu = (int)std::max<size_t>(1, std::min<size_t>(TPR_DP_BLOCKS_PER_CU, EXTEND_LDS_LIMIT / std::max<size_t>(1, extend_dp_lds_bytes(dp_x_cap, dp_y_cap))));
+  const int dp_blocks = tpr ? a->n_cu * dp_per_cu : 0;
+  // rows: [main | team | slow | control kernel's workgroups | the wave-per-read launch for what the control kernel leaves]
+  const int bail_blocks = tpr ? std::min(ext_blocks, a->n_cu) : 0;
+  const uint64_t tpr_rows = (uint64_t)ctl_blocks + (uint64_t)bail_blocks * 4;
   const uint64_t n_rows = main_rows + team_rows + slow_waves + tpr_rows;
   HIPCHK(a, a->e_wcnt.ensure(n_rows * THM_N_COUNTERS * 8 + 64));
   HIPCHK(a, hipMemsetAsync(a->e_wcnt.p, 0, n_rows * THM_N_COUNTERS * 8, s));
@@ -290,9 +295,32 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     HIPCHK(a, a->t_qlist.ensure(4 * rec_cap * 4 + 64));
     HIPCHK(a, a->t_act[0].ensure(n * 4 + 64));
     HIPCHK(a, a->t_act[1].ensure(n * 4 + 64));
+    HIPCHK(a, a->t_bail.ensure((n + 1) * 8));
+    HIPCHK(a, a->t_queue2.ensure(thm::QUEUE_BYTES));
+    HIPCHK(a, hipMemsetAsync(a->t_queue2.p, 0, thm::QUEUE_BYTES, s));
     HIPCHK(a, a->t_ctl.ensure(TPRC_BYTES));
     HIPCHK(a, hipMemsetAsync(a->t_ctl.p, 0, TPRC_BYTES, s));
     unsigned long long* ctl = a->t_ctl.as<unsigned long long>();
+    // The reads with HEAVY_HITS hits and more (the lists of plan_kernel) are the wave-per-read / workgroup-per-read
+    // kernels': they run BESIDE the rounds below, on their own streams.
+    {
+      ExtendParamsT<C> hp = ep;
+      hp.skip_scan = 1;
+      hp.team_limit = 16u * (uint32_t)a->n_cu;  // no scan of the batch to share the machine with: the team kernel keeps every read it can take
+      HIPCHK(a, hipEventRecord(a->ev_fork, s));
+      HIPCHK(a, hipStreamWaitEvent(a->stream2, a->ev_fork, 0));
+      HIPCHK(a, hipStreamWaitEvent(a->stream3, a->ev_fork, 0));
+      if (team_ok) {
+        ExtendParamsT<C> tp = hp;
+        tp.list_only = 1;
+        tp.wave_counters = ep.wave_counters + main_rows * THM_N_COUNTERS;
+        tp.trace_scratch = ep.trace_scratch + main_trace_waves * trace_per_wave / 8;
+        HIPCHK(a, launch_extend(tp, cpl, a->n_cu, a->stream2, true));
+      }
+      HIPCHK(a, launch_extend(hp, cpl, ext_blocks, a->stream3));
+      HIPCHK(a, hipEventRecord(a->ev_join, a->stream2));
+      HIPCHK(a, hipEventRecord(a->ev_join3, a->stream3));
+    }
     TprParamsT<C> tq;
     tq.recs_rw = a->e_recs.as<ReadRecT<C>>();
     tq.memos = a->t_memos.as<ReadMemo>();
@@ -305,8 +333,11 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     tq.q_list = a->t_qlist.as<uint32_t>();
     tq.q_stride = rec_cap;
     tq.q_cur = ctl + TPRC_Q_CUR;
-    tq.bail = ep.heavy == nullptr ? nullptr : const_cast<unsigned long long*>(ep.heavy);
-    tq.bail_count = const_cast<unsigned long long*>(ep.heavy_count);
+    tq.bail = a->t_bail.as<unsigned long long>();
+    tq.bail_count = ctl + TPRC_BAIL_CNT;
+    tq.team = nullptr;  // (the team kernel is running already; a read of this path has fewer hits than it takes anyway)
+    tq.team_count = nullptr;
+    tq.max_hits = TPR_MAX_HITS;
     tq.stats = ctl + TPRC_STATS;
     ExtendParamsT<C> zp = ep;
     zp.wave_counters = ep.wave_counters + (main_rows + team_rows + slow_waves) * THM_N_COUNTERS;
@@ -318,8 +349,17 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     dq.q_cur = ctl + TPRC_Q_CUR;
     dq.q_done = ctl + TPRC_Q_DONE;
     dq.fault = ep.fault;
-    dq.x_cap = (cls.fast_len + 64u + 15u) & ~15u;
-    dq.y_cap = (cls.fast_len + cls.fast_bw + 2u + 64u + 15u) & ~15u;
+    dq.x_cap = dp_x_cap;
+    dq.y_cap = dp_y_cap;
+    {
+      const size_t tb = extend_dp_trace_bytes(dp_y_cap, cpl);
+      HIPCHK(a, a->t_trace.ensure((size_t)dp_blocks * 4 * tb + 64));
+      dq.trace_scratch = a->t_trace.as<unsigned long long>();
+      dq.trace_per_wave = tb / 8;
+    }
+    // round 0's list: the reads of this path by descending hit count
+    HIPCHK(a, launch_tpr_order(a->e_recs.as<ReadRecT<C>>(), n, cls.fast_len, TPR_MAX_HITS, ctl + TPRC_BINS, a->t_act[0].as<uint32_t>(), ctl + TPRC_N_ACT,
+                               a->d_fault.as<int>(), s));
     const int n_rounds = a->tpr_rounds;  // rounds of requests a read may take (then: the wave-per-read kernel)
     for (int r = 0; r <= n_rounds; r++) {
       tq.round = (uint32_t)r;
@@ -330,15 +370,25 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
       tq.last_round = r == n_rounds ? 1u : 0u;
       HIPCHK(a, launch_extend_ctl(zp, tq, ctl_blocks, s));
       if (r == n_rounds) break;
-      for (int c = 1; c <= cpl; c++) {
-        dq.work = (unsigned int*)((uint8_t*)a->t_ctl.p + TPRC_WORK_BYTES + ((size_t)r * 4 + (size_t)(c - 1)) * 64);
-        HIPCHK(a, launch_extend_dp(dq, c, dp_blocks, s));
-      }
+      dq.work = (unsigned int*)((uint8_t*)a->t_ctl.p + TPRC_WORK_BYTES + (size_t)r * 4 * 64);
+      HIPCHK(a, launch_extend_dp(dq, cpl, dp_blocks, s));
       HIPCHK(a, hipMemcpyAsync(ctl + TPRC_Q_DONE, ctl + TPRC_Q_CUR, 32, hipMemcpyDeviceToDevice, s));
     }
-    ep.skip_scan = 1;
-  }
-  if (team_ok) {
+    // what the control kernel left (capacities, rounds): one more wave-per-read launch over that list, behind the others
+    HIPCHK(a, hipStreamWaitEvent(s, a->ev_join, 0));
+    HIPCHK(a, hipStreamWaitEvent(s, a->ev_join3, 0));
+    {
+      ExtendParamsT<C> bp = ep;
+      bp.skip_scan = 1;
+      bp.heavy = a->t_bail.as<unsigned long long>();
+      bp.heavy_count = ctl + TPRC_BAIL_CNT;
+      bp.team = nullptr;
+      bp.team_count = nullptr;
+      bp.queue = a->t_queue2.as<unsigned int>();
+      bp.wave_counters = zp.wave_counters + (uint64_t)ctl_blocks * THM_N_COUNTERS;
+      HIPCHK(a, launch_extend(bp, cpl, bail_blocks, s));
+    }
+  } else if (team_ok) {
     ExtendParamsT<C> tp = ep;
     tp.list_only = 1;
     tp.wave_counters = ep.wave_counters + main_rows * THM_N_COUNTERS;
@@ -435,6 +485,7 @@ int enqueue_run(thm_aligner* a) {
     }();
     pp.team_div = div_env * (uint32_t)std::max(a->n_cu, 1);
   }
+  pp.tpr_max_hits = (a->use_tpr && std::max(1, (int)((2 * cls.fast_bw + 1 + 63) / 64)) <= 4) ? TPR_MAX_HITS : 0u;
   pp.counts = a->s_work_counts.as<unsigned long long>();
   pp.read_status = a->r_status.as<int32_t>();
   pp.read_n_alns = a->e_nalns.as<uint32_t>();
@@ -580,7 +631,7 @@ int32_t thm_batch_sync(thm_aligner* a) {
     int rc = read_status(a, &st);
     if (rc != THM_OK) return rc;
     // a seed-pool overflow comes first: the extend kernel did not run on that attempt (its fault word means nothing)
-    if (!st.fault_seed && (st.fault_ext & 2)) return fail(a, THM_ERR_INTERNAL, "extend kernel reported an internal inconsistency");
+    if (!st.fault_seed && (st.fault_ext & 2)) return fail(a, THM_ERR_INTERNAL, "extend kernel reported an internal inconsistency (fault word 0x%x)", st.fault_ext);
     const bool grow = st.fault_seed || (st.fault_ext & 1);
     if (!grow) {
       float ms = 0;
