@@ -547,7 +547,7 @@ class Aligner:
 
     def debug_tpr_stats(self):
         """the last run's problem-parallel path (thm_debug_tpr_stats)"""
-        out = np.zeros(16, "<u8")
+        out = np.zeros(32, "<u8")
         self._chk(lib().thm_debug_tpr_stats(self.h, _ptr(out)))
         return out
 

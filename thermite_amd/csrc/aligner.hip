@@ -46,7 +46,12 @@ static int get_dev_copy(thm_aligner* a) {
       if (e == hipSuccess) e = upload(buf, vec, s);
     };
     d->wide = ix->wide;
-    up(d->text, ix->text);
+    // the text gets 16 bytes in front (left extensions are read in whole 8-byte words that may begin a few bytes before the
+    // first symbol; the window staging of the wave-per-read kernels rounds its addresses down to 16 bytes)
+    if (e == hipSuccess) e = d->text.ensure(ix->text.size() + 16 + 16);
+    if (e == hipSuccess) e = hipMemsetAsync(d->text.p, '$', 16, s);
+    if (e == hipSuccess && !ix->text.empty())
+      e = hipMemcpyAsync(d->text.as<uint8_t>() + 16, ix->text.data(), ix->text.size(), hipMemcpyHostToDevice, s);
     if (ix->wide) {
       up(d->sa, ix->sa64);
       up(d->lut, ix->lut64);
@@ -87,7 +92,7 @@ static int get_dev_copy(thm_aligner* a) {
     }
     auto fill_view = [&](auto& v) {
       typedef typename std::remove_reference<decltype(v)>::type::coord_t C;
-      v.text = d->text.as<uint8_t>();
+      v.text = d->text.as<uint8_t>() + 16;
       v.sa = d->sa.as<C>();
       v.lut = d->lut.as<LutEntryT<C>>();
       v.refs = d->refs.as<thm_ref>();
@@ -183,6 +188,9 @@ int32_t thm_aligner_create(const thm_index* ix, const thm_align_opts* opts, int3
     if (hipEventCreate(&e) != hipSuccess) return bail(fail(nullptr, THM_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&a->stream3, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&a->stream4, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&a->ev_dpt_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&a->ev_dpt_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&a->ev_join3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming) != hipSuccess)
@@ -205,8 +213,9 @@ void thm_aligner_free(thm_aligner* a) {
   if (a->stream) (void)hipStreamSynchronize(a->stream);
   if (a->stream2) (void)hipStreamSynchronize(a->stream2);
   if (a->stream3) (void)hipStreamSynchronize(a->stream3);
+  if (a->stream4) (void)hipStreamSynchronize(a->stream4);
   DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->d_cursors, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4,
-                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->e_wcnt, &a->t_memos, &a->t_recs, &a->t_dpops, &a->t_qlist, &a->t_act[0], &a->t_act[1], &a->t_ctl, &a->t_bail, &a->t_queue2, &a->t_trace, &a->s_smems, &a->s_off, &a->s_cnt,
+                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->e_wcnt, &a->t_memos, &a->t_recs, &a->t_dpops, &a->t_qlist, &a->t_act[0], &a->t_act[1], &a->t_ctl, &a->t_bail, &a->t_queue2, &a->t_trace, &a->t_ttrace, &a->t_hdr, &a->t_sums, &a->s_smems, &a->s_off, &a->s_cnt,
                  &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_order, &a->e_ops, &a->e_nalns,
                  &a->e_nalns64, &a->e_opbytes, &a->e_aln_off, &a->e_ops_off, &a->e_trace, &a->o_alns, &a->o_ops, &a->o_mems};
   for (DBuf* b : all) b->release();
@@ -221,6 +230,9 @@ void thm_aligner_free(thm_aligner* a) {
   if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
   if (a->ev_join) (void)hipEventDestroy(a->ev_join);
   if (a->ev_join3) (void)hipEventDestroy(a->ev_join3);
+  if (a->ev_dpt_fork) (void)hipEventDestroy(a->ev_dpt_fork);
+  if (a->ev_dpt_join) (void)hipEventDestroy(a->ev_dpt_join);
+  if (a->stream4) (void)hipStreamDestroy(a->stream4);
   if (a->stream3) (void)hipStreamDestroy(a->stream3);
   if (a->stream2) (void)hipStreamDestroy(a->stream2);
   if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -399,9 +411,10 @@ int32_t thm_debug_set_pool_caps(thm_aligner* a, uint64_t smem_cap, uint64_t cand
 
 // test / tuning hook.  flags bit 0: the problem-parallel path (kernels_tpr.hip) off -- every read takes the wave-per-read
 // kernels; bit 1: on (the parity tests run both ways); bits 8..11: rounds of requests (0: keep).
-// thm_debug_tpr_stats: 16 words of the last run -- [0] reads of the fast class left to the wave-per-read kernel,
-// [1..7] why (1 band, 2 grid, 3 lift, 6 capacity, 7 other), [8] DP requests, [9] DP op bytes reserved,
-// [10..13] requests by band class, [14] reads still waiting when the rounds ran out.
+// thm_debug_tpr_stats: 32 words of the last run -- [0] reads of the fast class left to the wave-per-read kernel,
+// [1..15] why (1 band, 2 grid, 3 lift, 7 other, 8 rounds / requests per round, 9 candidates, 10 ops beside Match, 11 introns,
+// 12 request pools, 13 window ends, 14 open targets), [16] DP requests, [17] of them narrow (thread-per-problem kernel),
+// [18..21] by band class, [22] reads still waiting when the rounds ran out.
 int32_t thm_debug_set_flags(thm_aligner* a, uint32_t flags) {
   if (!a) return THM_ERR_INVALID_ARG;
   if (flags & 1u) a->use_tpr = false;
@@ -410,19 +423,19 @@ int32_t thm_debug_set_flags(thm_aligner* a, uint32_t flags) {
   if (r >= 1 && r <= TPR_MAX_ROUNDS) a->tpr_rounds = r;
   return THM_OK;
 }
-int32_t thm_debug_tpr_stats(thm_aligner* a, uint64_t stats[16]) {
+int32_t thm_debug_tpr_stats(thm_aligner* a, uint64_t stats[32]) {
   if (!a || !stats) return THM_ERR_INVALID_ARG;
-  memset(stats, 0, 128);
+  memset(stats, 0, 256);
   if (!a->t_ctl.p) return THM_OK;
   HIPCHK(a, hipSetDevice(a->device));
   HIPCHK(a, hipStreamSynchronize(a->stream));
-  unsigned long long c[32];
+  unsigned long long c[40];
   HIPCHK(a, hipMemcpy(c, a->t_ctl.p, sizeof c, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 8; k++) stats[k] = c[TPRC_STATS + k];
-  stats[8] = c[TPRC_REC_CUR];
-  stats[9] = c[TPRC_DPO_CUR];
-  for (int k = 0; k < 4; k++) stats[10 + k] = c[TPRC_Q_CUR + k];
-  stats[14] = c[TPRC_N_ACT + a->tpr_rounds + 1];
+  for (int k = 0; k < 16; k++) stats[k] = c[TPRC_STATS + k];
+  stats[16] = c[TPRC_REC_CUR];
+  stats[17] = c[TPRC_Q_CUR];  // class 0: thread-per-problem kernel
+  for (int k = 0; k < 4; k++) stats[18 + k] = c[TPRC_Q_CUR + 1 + k];
+  stats[22] = c[TPRC_N_ACT + a->tpr_rounds + 1];
   return THM_OK;
 }
 

@@ -90,6 +90,8 @@ struct thm_aligner {
   hipStream_t stream2 = nullptr;  // the team kernel runs beside the wave-per-read kernel
   hipStream_t stream3 = nullptr;  // ... and both beside the rounds of the problem-parallel path
   hipEvent_t ev_join3 = nullptr;
+  hipStream_t stream4 = nullptr;  // the thread-per-problem DP kernel of a round runs beside the wave-per-problem one
+  hipEvent_t ev_dpt_fork = nullptr, ev_dpt_join = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   thm_align_opts opts;
   std::string err;
@@ -116,7 +118,7 @@ struct thm_aligner {
   // Extension problems as the unit of wavefront work (kernels_tpr.hip: thread-per-read control kernel + wave-per-request
   // DP kernel, in rounds), ahead of the wave-per-read kernels, which take what is left.  THM_TPR=0 or
   // thm_debug_set_flags turn it off (every read then takes the wave-per-read path); THM_TPR_ROUNDS = 1..8.
-  DBuf t_memos, t_recs, t_dpops, t_qlist, t_act[2], t_ctl, t_bail, t_queue2, t_trace;
+  DBuf t_memos, t_recs, t_dpops, t_qlist, t_act[2], t_ctl, t_bail, t_queue2, t_trace, t_ttrace, t_hdr, t_sums;
   bool use_tpr = false;  // (until the path is the faster one on the headline workload)
   int tpr_rounds = 8;
   uint64_t n_slow_host = 0;     // reads of the slow class in the last enqueue (host count)

@@ -231,42 +231,34 @@ struct Pend {
   uint16_t pad_;
 };
 
+// the ops of a path that are not Match: (path index << 2 | op kind), ascending
+constexpr int TPR_MAX_ED = 2 * DP_MAX_EDITS;
+struct EdList {
+  uint16_t e[TPR_MAX_ED];
+  int n;
+};
+
 // what the kernel keeps of an accepted candidate until the read is finished
 struct TCand {
   uint64_t ch0, ch1, ylen;  // chromosome coordinates
-  int score, xstart, xend, nops, nl, len;
-  int l_sp, r_sp, l_rec, r_rec;
+  int score, xstart, xend, nops;
+  uint16_t ed[TPR_MAX_ED];  // the path: rev(left.ops) ++ Match x len ++ right.ops (src/aligner.rs:388-394), Match but for these
   uint32_t ref_id, name_rank, type_idx;
   uint32_t mk_k[TPR_MAX_MK], ycl[TPR_MAX_MK];  // introns: path index they precede, length
   int tx_ystart, tx_yend;
   uint32_t tx_ylen;
-  uint8_t strand, aln_type, rev, n_y;
-};
-
-// op k of a candidate's path: rev(left.ops) ++ Match x len ++ right.ops (src/aligner.rs:388-394).  A DP record holds
-// its ops in traceback order (from the end cell back to the seed).
-struct PathView {
-  int nl, len, nops, l_sp, r_sp;
-  const uint8_t* l_ops;  // DP ops of the left extension (null: closed form)
-  const uint8_t* r_ops;
-  __device__ __forceinline__ uint8_t op(int k) const {
-    if (k < nl) return l_ops ? l_ops[k] : (uint8_t)((l_sp >= 0 && k == nl - 1 - l_sp) ? OPK_SUBST : OPK_MATCH);
-    if (k < nl + len) return (uint8_t)OPK_MATCH;
-    const int t = k - nl - len, nr = nops - nl - len;
-    return r_ops ? r_ops[nr - 1 - t] : (uint8_t)((r_sp >= 0 && t == r_sp) ? OPK_SUBST : OPK_MATCH);
-  }
+  uint8_t strand, aln_type, rev, n_y, n_ed;
 };
 
 // One op stream: [Xclip(lead)] path with introns [Xclip(trail)], mirrored as a list when `rev`
 // (kernels_extend.hip::emit_alignment).  Paths are Match almost everywhere: zero fill, then patches.
 // `o` is 4-byte aligned and the allocation is rounded up to 4 bytes.
-__device__ __forceinline__ void emit_stream(uint8_t* o, int total, const PathView& pv, int lead, int trail, bool rev, int n_y,
+__device__ __forceinline__ void emit_stream(uint8_t* o, int total, const uint16_t* ed, int n_ed, int lead, int trail, bool rev, int n_y,
                                             const uint32_t* mk_k, const uint32_t* ycl) {
   static_assert(OPK_MATCH == 0, "zero fill");
   uint32_t* o4 = (uint32_t*)o;
   for (int t = 0; t * 4 < total; t++) o4[t] = 0u;
   const int lead5 = lead > 0 ? 5 : 0;
-  auto put1 = [&](int fpos, uint8_t v) { o[rev ? total - (fpos + 1) : fpos] = v; };
   auto put5 = [&](int fpos, uint8_t kind, uint32_t v) {
     uint8_t* d = o + (rev ? total - (fpos + 5) : fpos);
     d[0] = kind;
@@ -275,34 +267,13 @@ __device__ __forceinline__ void emit_stream(uint8_t* o, int total, const PathVie
     d[3] = (uint8_t)(v >> 16);
     d[4] = (uint8_t)(v >> 24);
   };
-  auto before = [&](int k) {
-    int b = 0;
+  for (int i = 0; i < TPR_MAX_ED; i++) {
+    if (i >= n_ed) break;
+    const int k = (int)(ed[i] >> 2);
+    int b = 0;  // introns before op k
     for (int m = 0; m < TPR_MAX_MK; m++) b += (m < n_y && (int)mk_k[m] <= k) ? 1 : 0;
-    return b;
-  };
-  // the ops that are not Match
-  if (!pv.l_ops) {
-    if (pv.l_sp >= 0) {
-      const int k = pv.nl - 1 - pv.l_sp;
-      put1(lead5 + k + 5 * before(k), (uint8_t)OPK_SUBST);
-    }
-  } else {
-    for (int k = 0; k < pv.nl; k++) {
-      const uint8_t v = pv.l_ops[k];
-      if (v) put1(lead5 + k + 5 * before(k), v);
-    }
-  }
-  const int r0 = pv.nl + pv.len, nr = pv.nops - r0;
-  if (!pv.r_ops) {
-    if (pv.r_sp >= 0) {
-      const int k = r0 + pv.r_sp;
-      put1(lead5 + k + 5 * before(k), (uint8_t)OPK_SUBST);
-    }
-  } else {
-    for (int t = 0; t < nr; t++) {
-      const uint8_t v = pv.r_ops[nr - 1 - t];
-      if (v) put1(lead5 + r0 + t + 5 * before(r0 + t), v);
-    }
+    const int fpos = lead5 + k + 5 * b;
+    o[rev ? total - (fpos + 1) : fpos] = (uint8_t)(ed[i] & 3u);
   }
   for (int m = 0; m < TPR_MAX_MK; m++)
     if (m < n_y) put5(lead5 + (int)mk_k[m] + 5 * m, THM_OP_YCLIP, ycl[m]);
@@ -317,19 +288,19 @@ __device__ __forceinline__ void emit_stream(uint8_t* o, int total, const PathVie
 //   round 0: the reads are 0 .. n_reads; later rounds: the list the round before left (tp.act_in).
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-// quantities a workgroup allocates in one go: cand op bytes, records, DP op bytes, sleepers, bails to the heavy list,
-// bails to the team list, queue slots of the four band classes
-constexpr int NALLOC = 10;
-enum { A_OPS = 0, A_REC = 1, A_DPO = 2, A_ACT = 3, A_BAIL = 4, A_BAILT = 5, A_Q0 = 6 };
+// quantities a workgroup allocates in one go: cand op bytes, records, sleepers, bails to the heavy list,
+// bails to the team list, queue slots of the DP classes
+constexpr int NALLOC = 5 + DP_NQ;
+enum { A_OPS = 0, A_REC = 1, A_ACT = 2, A_BAIL = 3, A_BAILT = 4, A_Q0 = 5 };
 
-// everything one walk over a hit's extension problems produces
-template <class S, class C>
+// the outcome of one hit (align_seed_hit) as the control kernel assembles it from the hit's summary and its DP results
+template <class S>
 struct HitOut {
   TPath<S> gx, best;
   bool have_best, gx_dead;
-  uint32_t best_tx, best_ent, e0;  // e0: first exon-grid entry of the query (best_ent counts from it)
-  RefRecT<C> ref;
+  uint32_t best_tx, best_ent;  // transcript and exon-grid entry of the best target
   uint32_t ref_id;
+  S hr;
   unsigned calls, win;
   unsigned long long cells, cols;  // DP work of the results the hit used
   int why;
@@ -342,11 +313,11 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
   __shared__ unsigned long long s_cnt[THM_N_COUNTERS];
   __shared__ unsigned s_part[4][NALLOC];
   __shared__ unsigned long long s_base[NALLOC];
-  __shared__ unsigned s_stats[8];
+  __shared__ unsigned s_stats[16];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   if (threadIdx.x < THM_N_COUNTERS) s_cnt[threadIdx.x] = 0;
-  if (threadIdx.x < 8) s_stats[threadIdx.x] = 0;
+  if (threadIdx.x < 16) s_stats[threadIdx.x] = 0;
   __syncthreads();
   const auto& ix = p.ix;
   const uint64_t n_items = (uint64_t)*tp.n_act_in;  // round 0: the reads of this path by descending hit count (tpr_order_kernel)
@@ -394,42 +365,65 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
     const uint8_t* rd = p.reads.bases + rec.base_off;
     L = mine ? (int)rec.len : 0;
 
-    // the read's hits in align_read's order: SMEMs as listed, occurrences by descending suffix-array rank
-    auto load_sm = [&](uint32_t si) -> SmemT<C> {
-      SmemT<C> sm;
-      if (si == 0) {
-        sm.lo = rec.lo0;
-        sm.hi = rec.hi0;
-        sm.qpos = rec.qpos0;
-        sm.len = rec.len0;
-      } else {
-        sm = p.smems[rec.smem_off + si];
-      }
-      return sm;
-    };
-
-    // One walk over the extension problems of a hit, in the order the reference meets them.
+    // One hit, from its summary (kernels_hit.hip: everything about the hit that does not depend on band, X-drop and best
+    // score) and the state in force.
     //   compute  take the DP results from the memo and produce the hit's outcome; returns 1 when they are missing
     //   else     (a hit behind the frontier, asked for speculatively) only collect the problems
     // Problems whose results are missing are collected in pend[].  Order of the records of a hit: the unknown sides of
-    // the transcript targets in yield order (right, left), then those of the genome window -- which are requested only
-    // if the genome problem is not dead, known by then.
-    auto walk_hit = [&](const bool compute, const SmemT<C>& sm, const C rr, const bool first_occ, const int bw, const int xd, HitOut<S, C>& o) -> int {
-      const int mode = compute ? 0 : 1;
-      const int q = sm.qpos, len = sm.len;
-      const C hrc = first_occ ? rec.sa0 : ix.sa[rr - 1];
-      const S hr = (S)hrc;
-      idx_to_ref_thread<C>(ix, hrc, o.ref, o.ref_id);
-      const C qs = hrc, qe = (C)(hrc + (C)len);
-      // genome window (:212-215)
-      const S seq_start = max((hr > (S)(L + bw)) ? hr - (S)(L + bw) : (S)0, (S)o.ref.start);
-      const S seq_end = min(hr + (S)(len + L + bw), (S)o.ref.end - 1);
-      bool need = false;
-      o.calls = o.win = 0;
-      o.cells = o.cols = 0;
+    // the open transcript targets in yield order (right, left), then those of the genome window -- which are requested
+    // only if the genome problem is not dead, known by then.
+    auto walk_hit = [&](const bool compute, const uint64_t slot, const int bw, const int xd, HitOut<S>& o) -> int {
+      const HitSum* sp = tp.sums + slot;
+      const uint8_t flags = sp->flags;
       o.why = 0;
+      if (flags & HF_COMPLEX) {
+        o.why = sp->why;
+        return 2;
+      }
+      const S hr = (S)sp->hr;
+      const int q = sp->q, len = sp->len;
+      const HitSide hgr = sp->gr, hgl = sp->gl;
+      const int n_open = sp->n_open, n_tgt = sp->n_tgt;
+      o.hr = hr;
+      o.ref_id = sp->ref_id;
+      bool need = false, bad = false;
+      o.cells = o.cols = 0;
+      o.calls = 2u + 2u * (unsigned)n_tgt;
+      const int xr = L - (q + len), xl = q;
+      // window bytes: the genome window (:212-215) and the targets' (see HitSum::win_*)
+      {
+        const unsigned lb = (unsigned)(L + bw);
+        unsigned w = (unsigned)len + min(lb, hgr.A) + min(lb, hgl.A);
+        w += sp->win_fixed + (unsigned)sp->win_nl * lb + (unsigned)sp->win_nr * (lb + 1u);
+        const int nvl = sp->win_nvl, nvr = sp->win_nvr;
+        for (int k = 0; k < HIT_MAX_VAR; k++) {
+          if (k < nvl) w += min((unsigned)sp->win_var[k], lb);
+          else if (k < nvl + nvr) w += min((unsigned)sp->win_var[k], lb + 1u);
+        }
+        o.win = w;
+      }
+      // a side as the summary classified it, under the X-drop in force
+      auto mk_side = [&](const HitSide& hs, int xlen) -> Side {
+        Side s;
+        s.score = s.xend = s.yend = s.n = 0;
+        s.sp = -1;
+        s.rec = -1;
+        s.ub = 0;
+        s.known = true;
+        if (hs.kind == SK_SHORTCUT) {
+          if (xd < 1) bad = true;  // (the shortcut needs x_drop >= 1: the wave-per-read kernels take such a read)
+          s.score = s.ub = xlen - 2;
+          s.xend = s.yend = s.n = xlen;
+          s.sp = 0;
+        } else if (hs.kind > SK_SHORTCUT) {
+          s.known = false;
+          s.ub = hs.kind == SK_UNK_DEL ? xlen - 1 : (hs.kind == SK_UNK ? max(xlen - 2, 0) : xlen);
+        }
+        return s;
+      };
       // an extension that needs a DP: its result from the memo, or one more problem to ask for
-      auto unknown_side = [&](Side& s, const uint8_t* x0, const uint8_t* y0, int dir, int xlen, long long ylen) {
+      auto unknown_side = [&](Side& s, const uint8_t* x0, const uint8_t* y0, int dir, int xlen, unsigned A) {
+        const int ylen = (int)min(A, (unsigned)(xlen + bw + 1));
         const int slots = min(2 * bw + 1, xlen + 1);
         if (compute) {
           const unsigned od = ord_r++;
@@ -460,31 +454,11 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
           e.xlen = (uint16_t)xlen;
           e.ylen = (uint16_t)ylen;
           e.dir = (int8_t)dir;
-          e.cls = (uint8_t)((slots + 63) / 64);
+          e.cls = (slots <= DPT_SLOTS && (uint32_t)ylen + 1u <= tp.dpt_cols) ? (uint8_t)0 : (uint8_t)((slots + 63) / 64);
           e.pad_ = 0;
         } else {
           pend_over = true;
         }
-      };
-      // the two sides of extend_left_right (src/aligner.rs:352-407) for a target spanning [lo_abs, hi_abs)
-      struct LrGeom {
-        const uint8_t *xr0, *yr0, *xl0, *yl0;
-        int xr, xl;
-        long long yr, yl;
-      };
-      auto lr_geom = [&](const uint8_t* ybase, S lo_abs, S hi_abs, S r, int q2, int len2) -> LrGeom {
-        LrGeom g;
-        g.xr = L - (q2 + len2);
-        g.yr = min((long long)(hi_abs - (r + len2)), (long long)(g.xr + bw + 1));
-        g.xr0 = rd + q2 + len2;
-        g.yr0 = ybase + (r + len2);
-        g.xl = q2;
-        const S rel = r - lo_abs;
-        const S y0 = lo_abs + (rel > (S)(L + bw) ? rel - (S)(L + bw) : (S)0);
-        g.yl = min((long long)(r - y0), (long long)(g.xl + bw + 1));
-        g.xl0 = rd + q2 - 1;
-        g.yl0 = ybase + (r - 1);
-        return g;
       };
       auto finish_path = [&](TPath<S>& t, S r, int q2, int len2) {
         t.nl = t.l.n;
@@ -496,155 +470,95 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         t.xstart = q2 - t.l.xend;
         t.xend = q2 + len2 + t.r.xend;
       };
-      // ---- genome window: classified now, requested (if at all) behind the transcript targets ----
-      o.win += (unsigned)(seq_end - seq_start);
-      o.calls += 2;
-      const LrGeom gg = lr_geom(ix.text, seq_start, seq_end, hr, q, len);
-      o.gx.r = side_classify(gg.xr0, gg.yr0, 1, gg.xr, gg.yr, xd);
-      o.gx.l = side_classify(gg.xl0, gg.yl0, -1, gg.xl, gg.yl, xd);
+      o.gx.r = mk_side(hgr, xr);
+      o.gx.l = mk_side(hgl, xl);
       const bool gx_known = o.gx.l.known && o.gx.r.known;
       const int gx_ub = o.gx.l.ub + len * MATCH_SCORE + o.gx.r.ub;
-      // exon_to_tx.find(seed) in yield order (:231-258): by ascending pre-order rank.  A bin's entries are sorted by
-      // rank, a seed spans one bin or two: a merge of two sorted lists, skipping what does not overlap and the second
-      // copy of an interval listed in both bins.
-      const uint32_t b0 = (uint32_t)(qs >> GRID_SHIFT), b1 = (uint32_t)((qe > qs ? qe - 1 : qs) >> GRID_SHIFT);
-      const uint32_t e0 = ix.exon_grid_off[b0], e1 = ix.exon_grid_off[b1 + 1];
-      const uint32_t emid = (b1 == b0) ? e1 : ix.exon_grid_off[b0 + 1];
-      const ExonEntryT<C>* ent = ix.exon_grid;
-      o.e0 = e0;
-      if (e1 - e0 > (uint32_t)TPR_MAX_ENT || b1 > b0 + 1) {
-        o.why = 2;
-        return 2;
+      // ---- the open targets: each unknown side is the genome window's problem again (same x, same number of y symbols,
+      // the same symbols: one DP serves both), or a problem of its own ----
+      TPath<S> op[HIT_MAX_OPEN];
+      HitTgt ot[HIT_MAX_OPEN];
+      bool al_r[HIT_MAX_OPEN], al_l[HIT_MAX_OPEN];
+      bool any_alias = false;
+      for (int j = 0; j < HIT_MAX_OPEN; j++) {
+        al_r[j] = al_l[j] = false;
+        if (j >= n_open) continue;
+        const HitTgt T = sp->open[j];
+        ot[j] = T;
+        const int t_q = T.t_q, t_len = T.t_len, t_xr = L - (t_q + t_len), t_xl = t_q;
+        const uint8_t* seq = nullptr;
+        op[j].r = mk_side(T.r, t_xr);
+        op[j].l = mk_side(T.l, t_xl);
+        if (!op[j].r.known) {
+          const unsigned X = (unsigned)(t_xr + bw + 1), yl = min(T.r.A, X);
+          if (!o.gx.r.known && t_q + t_len == q + len && yl == min(hgr.A, X) && (unsigned)T.r.eq >= yl) {
+            al_r[j] = any_alias = true;
+          } else {
+            seq = ix.tx_seq + ix.exon_grid[T.ent].seq_off;
+            unknown_side(op[j].r, rd + t_q + t_len, seq + (T.tr + t_len), 1, t_xr, T.r.A);
+          }
+        }
+        if (!op[j].l.known) {
+          const unsigned X = (unsigned)(t_xl + bw + 1), yl = min(T.l.A, X);
+          if (!o.gx.l.known && t_q == q && yl == min(hgl.A, X) && (unsigned)T.l.eq >= yl) {
+            al_l[j] = any_alias = true;
+          } else {
+            if (!seq) seq = ix.tx_seq + ix.exon_grid[T.ent].seq_off;
+            unknown_side(op[j].l, rd + t_q - 1, seq + (T.tr - 1), -1, t_xl, T.l.A);
+          }
+        }
       }
-      uint32_t gi = e0, gj = emid;  // cursors of the two lists
-      auto grid_skip = [&](uint32_t& t, uint32_t end) {
-        while (t < end) {
-          const C es = ent[t].start, ee = ent[t].end;
-          const uint32_t home = max(b0, (uint32_t)(es >> GRID_SHIFT));
-          if (qs < ee && es < qe && (ent[t].rank & 0xffu) == (home & 0xffu)) break;
-          t++;
-        }
-      };
-      o.have_best = false;
-      o.best_tx = o.best_ent = 0;
-      int known_best = -1;  // best score among the targets known in closed form
-      // the first target that is the genome problem again while that is not known yet: its score comes with the genome's
-      bool alias = false;
-      int alias_pos = 0, best_pos = 0, pos = 0;
-      uint32_t alias_tx = 0, alias_ent = 0;
-      int alias_tr = 0;
-      bool stop = false;
-      while (!stop) {
-        grid_skip(gi, emid);
-        grid_skip(gj, e1);
-        uint32_t ei;
-        if (gi < emid && (gj >= e1 || ent[gi].rank <= ent[gj].rank))
-          ei = gi++;
-        else if (gj < e1)
-          ei = gj++;
-        else
-          break;
-        const ExonEntryT<C> ge = ent[ei];
-        if (!(ge.prev_end <= qs)) {  // lift_mem_to_tx's general case (a seed across a short intron)
-          o.why = 3;
-          return 2;
-        }
-        // lift_mem_to_tx (src/txome.rs:82-103)
-        const S xs = (S)ge.start, xe = (S)ge.end;
-        const int exon_sum = (int)ge.txoff;
-        int tr_ = (int)((hr > xs) ? hr - xs : (S)0) + exon_sum;
-        const int start_offset = (int)((xs > hr) ? xs - hr : (S)0);
-        const int t_end = (int)(min(hr + (S)len, xe) - xs) + exon_sum;
-        int t_q = q + start_offset;
-        int t_len = t_end - tr_;
-        const int tlen = (int)ge.seq_len;
-        const int ws = (tr_ > L + bw) ? tr_ - (L + bw) : 0;
-        const int we = min(tlen, tr_ + t_len + L + bw + 1);
-        o.win += (unsigned)(we - ws);
-        o.calls += 2;
-        const uint8_t* seq = ix.tx_seq + ge.seq_off;
-        // extend_seed_match (src/aligner.rs:410-426)
-        {
-          int ext = match_fwd(seq + tr_ + t_len, rd + t_q + t_len, min(tlen - (tr_ + t_len), L - (t_q + t_len)));
-          t_len += ext;
-          ext = match_bwd(seq + tr_, rd + t_q, min(tr_, t_q));
-          tr_ -= ext;
-          t_q -= ext;
-          t_len += ext;
-        }
-        const LrGeom tg = lr_geom(seq, (S)0, (S)tlen, (S)tr_, t_q, t_len);
-        // Same seed on the read and the same y bytes as the genome problem (the hit lies inside one exon that covers
-        // both windows): the two extend() calls have the genome calls' inputs, hence its results.
-        // (With a genome problem known in closed form the target's sides are simply classified: same bytes, same answer.)
-        bool same = false;
-        if (!gx_known && t_q == q && t_len == len && tg.yr == gg.yr && tg.yl == gg.yl) {
-          same = (gg.xr == 0 || gg.yr <= 0 || match_fwd(tg.yr0, gg.yr0, (int)gg.yr) == (int)gg.yr) &&
-                 (gg.xl == 0 || gg.yl <= 0 || match_fwd(tg.yl0 + 1 - (int)gg.yl, gg.yl0 + 1 - (int)gg.yl, (int)gg.yl) == (int)gg.yl);
-        }
-        TPath<S> pth;
-        bool p_known, p_scored = true;  // scored: the target's score is in pth.score now
-        if (same) {
-          pth.l = o.gx.l;
-          pth.r = o.gx.r;
-          p_known = false;
-          p_scored = false;
-          if (!alias) {
-            alias = true;
-            alias_pos = pos;
-            alias_tx = ge.value;
-            alias_ent = ei - e0;
-            alias_tr = tr_;
-          }
-        } else {
-          pth.r = side_classify(tg.xr0, tg.yr0, 1, tg.xr, tg.yr, xd);
-          if (!pth.r.known) unknown_side(pth.r, tg.xr0, tg.yr0, 1, tg.xr, tg.yr);
-          pth.l = side_classify(tg.xl0, tg.yl0, -1, tg.xl, tg.yl, xd);
-          if (!pth.l.known) unknown_side(pth.l, tg.xl0, tg.yl0, -1, tg.xl, tg.yl);
-          p_known = pth.l.known && pth.r.known;
-        }
-        if (p_known) {
-          finish_path(pth, (S)tr_, t_q, t_len);
-          known_best = max(known_best, pth.score);
-        }
-        if (mode == 0 && !need && p_scored) {
-          if (!p_known) finish_path(pth, (S)tr_, t_q, t_len);
-          if (!o.have_best || pth.score > o.best.score) {  // strictly better (:249)
-            o.have_best = true;
-            o.best_tx = ge.value;
-            o.best_ent = ei - e0;
-            o.best = pth;
-            best_pos = pos;
-          }
-        }
-        // cannot beat an exact match (:253-257); a target that needs a DP scores below L
-        if (p_known && pth.score >= L * MATCH_SCORE) stop = true;
-        pos++;
+      // ---- the best target known in closed form ----
+      TPath<S> kn;
+      HitTgt kt;
+      int known_score = -1;
+      const bool has_known = (flags & HF_KNOWN) != 0;
+      if (has_known) {
+        kt = sp->known;
+        kn.r = mk_side(kt.r, L - ((int)kt.t_q + (int)kt.t_len));
+        kn.l = mk_side(kt.l, (int)kt.t_q);
+        finish_path(kn, (S)kt.tr, (int)kt.t_q, (int)kt.t_len);
+        known_score = kn.score;
       }
       // ---- the genome problem: dead when a target known in closed form reaches its upper bound and no target takes
       // its result (it is not computed then and takes no records); else its unknown sides are the hit's last requests ----
-      o.gx_dead = !gx_known && !alias && known_best >= gx_ub;
+      o.gx_dead = !gx_known && !any_alias && has_known && known_score >= gx_ub;
       if (!o.gx_dead) {
-        if (!o.gx.r.known) unknown_side(o.gx.r, gg.xr0, gg.yr0, 1, gg.xr, gg.yr);
-        if (!o.gx.l.known) unknown_side(o.gx.l, gg.xl0, gg.yl0, -1, gg.xl, gg.yl);
+        if (!o.gx.r.known) unknown_side(o.gx.r, rd + q + len, ix.text + (hr + len), 1, xr, hgr.A);
+        if (!o.gx.l.known) unknown_side(o.gx.l, rd + q - 1, ix.text + (hr - 1), -1, xl, hgl.A);
       }
+      if (bad) o.why = 7;
       if (o.why) return 2;
-      if (mode != 0) return 0;
+      if (!compute) return 0;
       if (need) return 1;
       finish_path(o.gx, hr, q, len);  // (a dead genome problem: never looked at)
-      if (alias) {
-        // the deferred target: the genome's result in transcript coordinates; earlier in yield order wins ties (:249)
-        TPath<S> a = o.gx;
-        a.ystart = (S)alias_tr - (S)o.gx.l.yend;
-        a.yend = (S)alias_tr + (S)len + (S)o.gx.r.yend;
-        if (!o.have_best || a.score > o.best.score || (a.score == o.best.score && alias_pos < best_pos)) {
+      // ---- the best target: the first of the best in yield order (strictly better wins, :249) ----
+      o.have_best = false;
+      o.best_tx = o.best_ent = 0;
+      uint32_t best_pos = 0;
+      if (has_known) {
+        o.have_best = true;
+        o.best = kn;
+        o.best_tx = kt.tx;
+        o.best_ent = kt.ent;
+        best_pos = kt.pos;
+      }
+      for (int j = 0; j < HIT_MAX_OPEN; j++) {
+        if (j >= n_open) continue;
+        if (al_r[j]) op[j].r = o.gx.r;
+        if (al_l[j]) op[j].l = o.gx.l;
+        finish_path(op[j], (S)ot[j].tr, (int)ot[j].t_q, (int)ot[j].t_len);
+        if (!o.have_best || op[j].score > o.best.score || (op[j].score == o.best.score && ot[j].pos < best_pos)) {
           o.have_best = true;
-          o.best_tx = alias_tx;
-          o.best_ent = alias_ent;
-          o.best = a;
+          o.best = op[j];
+          o.best_tx = ot[j].tx;
+          o.best_ent = ot[j].ent;
+          best_pos = ot[j].pos;
         }
       }
       return 0;
     };
+
     if (mine) {
       cand0 = rec.cand_off;
       if (cand0 + rec.n_hits > p.cand_cap) {
@@ -665,11 +579,10 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
           bail = true;
           why = 1;
         }
-        uint32_t n_acc = 0, hno = 0;
-        const uint32_t n_sm = rec.smem_cnt;
-        for (uint32_t si = 0; !bail && !sleep && si < n_sm; si++) {
-          const SmemT<C> sm = load_sm(si);
-          for (C rr = sm.hi; !bail && !sleep && rr > sm.lo; rr--, hno++) {
+        uint32_t n_acc = 0;
+        const uint32_t n_hits = rec.n_hits;
+        for (uint32_t hno = 0; !bail && !sleep && hno < n_hits; hno++) {
+          {
             // ================= align_seed_hit (src/aligner.rs:198-314) =================
             const int bw = band_width, xd = x_drop;
             // a round of the memo that was requested from this hit on: its records are for the state in force now
@@ -678,8 +591,8 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
               ord_r = 0;
               round_ok = true;
             }
-            HitOut<S, C> h;
-            const int st = walk_hit(true, sm, rr, si == 0 && rr == sm.hi, bw, xd, h);
+            HitOut<S> h;
+            const int st = walk_hit(true, cand0 + hno, bw, xd, h);
             if (st == 2) {
               bail = true;
               why = h.why;
@@ -689,29 +602,18 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
               // results are missing: this hit is the round's frontier; its problems are in pend[]
               if (memo.n_rounds >= TPR_MAX_ROUNDS || tp.last_round != 0 || pend_over || n_pend == 0) {
                 bail = true;
-                why = 6;
+                why = 8;
                 break;
               }
-              // While no candidate has been accepted the state is the wide initial one and the first acceptance
-              // will narrow it: ask for few hits (1, 2, 4, ...).  After that it rarely moves: all the remaining hits,
-              // as far as pend[] holds their problems.  A hit behind the frontier that this path cannot take ends the
+              // The first hit of a read usually is accepted and narrows the wide initial band: it is asked for alone.
+              // After that the state rarely moves (and a read whose first hit was rejected tends to reject the
+              // others too): all the remaining hits, as far as pend[] holds their problems.  A hit behind the frontier that this path cannot take ends the
               // batch; if the replay gets there it asks again, or leaves the read to the wave-per-read kernel.
-              uint32_t left = n_acc > 0 ? 0xFFFFFFFFu : (1u << min((int)memo.n_rounds, 5));
-              uint32_t si2 = si;
-              SmemT<C> sm2 = sm;
-              C rr2 = rr;
-              while (--left) {
-                rr2--;
-                while (rr2 <= sm2.lo) {  // next SMEM with occurrences
-                  si2++;
-                  if (si2 >= n_sm) break;
-                  sm2 = load_sm(si2);
-                  rr2 = sm2.hi;
-                }
-                if (si2 >= n_sm) break;
+              uint32_t left = (n_acc > 0 || memo.n_rounds > 0) ? 0xFFFFFFFFu : 1u;
+              for (uint32_t h2 = hno + 1; --left && h2 < n_hits; h2++) {
                 const int mark = n_pend;
-                HitOut<S, C> h2;
-                const int st2 = walk_hit(false, sm2, rr2, false, bw, xd, h2);
+                HitOut<S> hb;
+                const int st2 = walk_hit(false, cand0 + h2, bw, xd, hb);
                 if (st2 == 2 || pend_over) {
                   n_pend = mark;
                   pend_over = false;
@@ -728,7 +630,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
             winbytes += h.win;
             dp_cells += h.cells;
             dp_cols += h.cols;
-            const ExonEntryT<C>* ent = ix.exon_grid + h.e0;
+            const ExonEntryT<C>* ent = ix.exon_grid;  // (best_ent is the entry's index in the whole grid)
             // ---- exonic vs unspliced (:263-313) ----
             const bool exonic = h.have_best && (h.gx_dead || h.best.score >= h.gx.score);
             const TPath<S>& sel = exonic ? h.best : h.gx;
@@ -739,7 +641,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
             if (!accept) continue;
             if (n_acc >= (uint32_t)TPR_KEEP) {
               bail = true;
-              why = 6;
+              why = 9;
               break;
             }
             TCand k;
@@ -748,12 +650,45 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
             k.tx_ylen = 0;
             for (int m = 0; m < TPR_MAX_MK; m++) k.mk_k[m] = k.ycl[m] = 0;
             k.nops = sel.nops;
-            k.nl = sel.nl;
-            k.len = sel.len;
-            k.l_sp = sel.l.sp;
-            k.r_sp = sel.r.sp;
-            k.l_rec = sel.l.rec;
-            k.r_rec = sel.r.rec;
+            // the path's ops that are not Match: rev(left.ops) ++ Match x len ++ right.ops (:388-394); a DP result lists
+            // its own from the end cell back to the seed -- the path's order on the left, the reverse of it on the right
+            int n_ed = 0, n_ins = 0;
+            {
+              bool over = false;
+              auto add = [&](int kpath, unsigned kind) {
+                if (n_ed < TPR_MAX_ED) k.ed[n_ed] = (uint16_t)((kpath << 2) | (int)kind);
+                n_ed++;
+                n_ins += kind == (unsigned)OPK_INS;
+              };
+              for (int t = 0; t < TPR_MAX_ED; t++) k.ed[t] = 0;
+              if (sel.l.rec >= 0) {
+                const DpRec* d = tp.recs + sel.l.rec;
+                const unsigned ne = d->n_edits;
+                const uint16_t* e = (const uint16_t*)d;
+                if (ne > (unsigned)DP_MAX_EDITS) over = true;
+                for (unsigned i = 0; i < (unsigned)DP_MAX_EDITS; i++)
+                  if (i < ne && !over) add((int)(e[i] >> 2), e[i] & 3u);
+              } else if (sel.l.sp >= 0) {
+                add(sel.nl - 1 - sel.l.sp, (unsigned)OPK_SUBST);
+              }
+              const int r0 = sel.nl + sel.len, nr = sel.nops - r0;
+              if (sel.r.rec >= 0) {
+                const DpRec* d = tp.recs + sel.r.rec;
+                const unsigned ne = d->n_edits;
+                const uint16_t* e = (const uint16_t*)d;
+                if (ne > (unsigned)DP_MAX_EDITS) over = true;
+                for (int i = DP_MAX_EDITS - 1; i >= 0; i--)
+                  if ((unsigned)i < ne && !over) add(r0 + (nr - 1 - (int)(e[i] >> 2)), e[i] & 3u);
+              } else if (sel.r.sp >= 0) {
+                add(r0 + sel.r.sp, (unsigned)OPK_SUBST);
+              }
+              if (over || n_ed > TPR_MAX_ED) {  // more ops beside Match than a candidate keeps: the wave-per-read kernels take the read
+                bail = true;
+                why = 10;
+                break;
+              }
+            }
+            k.n_ed = (uint8_t)n_ed;
             S cy0, cy1;
             int aln_type;
             uint32_t type_idx = THM_NO_IDX;
@@ -774,14 +709,6 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
                 cy0 = (S)ge.start + (S)(ys_ - e_lo);
                 cy1 = (S)ge.start + (S)(ye_ - e_lo);
               } else {
-                PathView pv;
-                pv.nl = best.nl;
-                pv.len = best.len;
-                pv.nops = best.nops;
-                pv.l_sp = best.l.sp;
-                pv.r_sp = best.r.sp;
-                pv.l_ops = best.l.rec >= 0 ? tp.dp_ops + tp.recs[best.l.rec].ops_off : nullptr;
-                pv.r_ops = best.r.rec >= 0 ? tp.dp_ops + tp.recs[best.r.rec].ops_off : nullptr;
                 const thm_tx tx = ix.txs[h.best_tx];
                 const thm_exon* ex = ix.exons + tx.exon_begin;
                 const uint64_t* toff = ix.exon_txoff + tx.exon_begin;
@@ -796,13 +723,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
                 }
                 int e = lo;
                 // transcript positions advance on Match / Subst / Del; their number must be yend - ystart (:154)
-                int n_adv = 0;
-                const bool all_adv = !pv.l_ops && !pv.r_ops;
-                if (all_adv) {
-                  n_adv = best.nops;
-                } else {
-                  for (int kk = 0; kk < best.nops; kk++) n_adv += pv.op(kk) != OPK_INS;
-                }
+                const int n_adv = best.nops - n_ins;
                 if (e >= ne || n_adv != ye_ - ys_) {  // panics in the reference: the wave-per-read kernel reports them
                   bail = true;
                   why = 7;
@@ -813,26 +734,19 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
                 cy0 = (S)cur.start + (S)(ys_ - xsum);
                 const bool trailing_clip = best.xend < L;
                 int n_y = 0;
-                int scan_k = 0, scan_adv = 0;  // ops [0, scan_k) hold scan_adv advancing ones
                 for (;;) {
                   const int bnd = xsum + (int)(cur.end - cur.start);
                   if (e + 1 >= ne || bnd > ye_) break;
                   const int need_adv = bnd - ys_;  // 1-based rank, among the advancing ops, of the op that reaches bnd
-                  int kstar;
-                  if (all_adv) {
-                    kstar = need_adv;
-                  } else {
-                    while (scan_adv < need_adv && scan_k < best.nops) {
-                      scan_adv += pv.op(scan_k) != OPK_INS;
-                      scan_k++;
-                    }
-                    kstar = scan_adv == need_adv ? scan_k : -1;
-                  }
-                  if (kstar < 0) break;
+                  // the index behind that op: every Ins before it moves it on by one
+                  int kstar = need_adv;
+                  for (int i = 0; i < TPR_MAX_ED; i++)
+                    if (i < n_ed && (k.ed[i] & 3u) == (unsigned)OPK_INS && (int)(k.ed[i] >> 2) < kstar) kstar++;
+                  if (need_adv > n_adv) break;  // (cannot happen with a consistent count)
                   if (kstar >= best.nops && !trailing_clip) break;
                   if (n_y >= TPR_MAX_MK) {
                     bail = true;
-                    why = 6;
+                    why = 11;
                     break;
                   }
                   const thm_exon nxt = ex[e + 1];
@@ -875,8 +789,9 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
               }
             }
             // concat_to_chr_aln (:429-449)
-            RefRecT<C> cref = h.ref;
-            if (!((C)cy0 >= h.ref.start && (C)cy0 < h.ref.end)) {
+            const RefRecT<C> href = ix.ref_recs[h.ref_id];  // Index::idx_to_ref(hit), looked up by the summary kernel
+            RefRecT<C> cref = href;
+            if (!((C)cy0 >= href.start && (C)cy0 < href.end)) {
               uint32_t dummy;
               idx_to_ref_thread<C>(ix, (C)cy0, cref, dummy);
             }
@@ -894,9 +809,9 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
             k.xstart = sel.xstart;
             k.xend = sel.xend;
             k.ref_id = h.ref_id;
-            k.name_rank = h.ref.name_rank;
+            k.name_rank = href.name_rank;
             k.type_idx = type_idx;
-            k.strand = h.ref.strand != 0 ? 1 : 0;
+            k.strand = href.strand != 0 ? 1 : 0;
             k.aln_type = (uint8_t)aln_type;
             cd[n_acc] = k;
             n_acc++;
@@ -995,8 +910,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       want[A_REC] = (unsigned)n_pend;
       want[A_ACT] = 1;
       for (int t = 0; t < n_pend; t++) {
-        want[A_DPO] += ((unsigned)pend[t].xlen + (unsigned)pend[t].ylen + 3u) & ~3u;
-        want[A_Q0 + pend[t].cls - 1]++;
+        want[A_Q0 + pend[t].cls]++;
       }
     }
     if (bail) want[bail_team ? A_BAILT : A_BAIL] = 1;
@@ -1016,11 +930,10 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       const unsigned tot = s_part[0][a2] + s_part[1][a2] + s_part[2][a2] + s_part[3][a2];
       unsigned long long* cur = a2 == A_OPS ? p.ops_cursor
                                 : a2 == A_REC ? tp.rec_cursor
-                                : a2 == A_DPO ? tp.dp_ops_cursor
                                 : a2 == A_ACT ? tp.n_act_out
                                 : a2 == A_BAIL ? tp.bail_count
                                 : a2 == A_BAILT ? tp.team_count
-                                                : &tp.q_cur[a2 - A_Q0];
+                                                : &tp.q_cur[a2 - A_Q0];  // (a2 - A_Q0 < DP_NQ)
       s_base[a2] = (tot && cur) ? atomicAdd(cur, (unsigned long long)tot) : 0ull;
     }
     __syncthreads();
@@ -1039,19 +952,19 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
     if (!pool_ok && threadIdx.x == 0 && blk_end[A_OPS] > s_base[A_OPS]) atomicOr(p.fault, FAULT_OPS_POOL);  // the host grows the pool and replays the batch
     if (!pool_ok) done = false;
     // request pools exhausted: the read goes to the wave-per-read kernel instead (no replay needed)
-    const bool req_ok = blk_end[A_REC] <= tp.rec_cap && blk_end[A_REC] < 0x7FFFFF00ull && blk_end[A_DPO] <= tp.dp_ops_cap &&
+    const bool req_ok = blk_end[A_REC] <= tp.rec_cap && blk_end[A_REC] < 0x7FFFFF00ull &&
                         blk_end[A_Q0] <= tp.q_stride && blk_end[A_Q0 + 1] <= tp.q_stride && blk_end[A_Q0 + 2] <= tp.q_stride &&
-                        blk_end[A_Q0 + 3] <= tp.q_stride;
+                        blk_end[A_Q0 + 3] <= tp.q_stride && blk_end[A_Q0 + 4] <= tp.q_stride;
     if (sleep && !req_ok) {
       sleep = false;
       const unsigned long long slot = atomicAdd(tp.bail_count, 1ull);  // (a late bail has no slot of this pass's allocation)
       tp.bail[slot] = idx;
-      why = 6;
+      why = 12;
       tp.act_out[mine_at[A_ACT]] = 0xFFFFFFFFu;  // its slot in the next round's list stays: marked empty
       {  // ... and so do its slots in the DP queues (as far as they lie inside the lists)
-        unsigned long long qs4[4] = {mine_at[A_Q0], mine_at[A_Q0 + 1], mine_at[A_Q0 + 2], mine_at[A_Q0 + 3]};
+        unsigned long long qs4[DP_NQ] = {mine_at[A_Q0], mine_at[A_Q0 + 1], mine_at[A_Q0 + 2], mine_at[A_Q0 + 3], mine_at[A_Q0 + 4]};
         for (int t = 0; t < n_pend; t++) {
-          const int c2 = pend[t].cls - 1;
+          const int c2 = pend[t].cls;
           if (qs4[c2] < tp.q_stride) tp.q_list[(size_t)c2 * tp.q_stride + qs4[c2]] = 0xFFFFFFFFu;
           qs4[c2]++;
         }
@@ -1066,7 +979,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
     if (sleep) {
       tp.act_out[mine_at[A_ACT]] = (uint32_t)idx;
       // ---- the collected problems become records, queued by band class ----
-      unsigned long long dpo = mine_at[A_DPO], qs4[4] = {mine_at[A_Q0], mine_at[A_Q0 + 1], mine_at[A_Q0 + 2], mine_at[A_Q0 + 3]};
+      unsigned long long qs4[DP_NQ] = {mine_at[A_Q0], mine_at[A_Q0 + 1], mine_at[A_Q0 + 2], mine_at[A_Q0 + 3], mine_at[A_Q0 + 4]};
       const unsigned long long w_rec = mine_at[A_REC];
       const unsigned w_n = (unsigned)n_pend;
       for (int t = 0; t < n_pend; t++) {
@@ -1074,14 +987,14 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         DpRec d;
         d.x0 = e.x0;
         d.y0 = e.y0;
-        d.ops_off = dpo;
+        d.pad0_ = 0;
         d.xlen = e.xlen;
         d.ylen = e.ylen;
         d.bw = (uint16_t)f_bw;
         d.xd = (uint16_t)min(f_xd, 65535);
         d.dir = e.dir;
         d.cls = e.cls;
-        d.pad_ = 0;
+        d.n_edits = 0;
         d.read = (uint32_t)idx;
         d.score = 0;
         d.xend = d.yend = d.nops = 0;
@@ -1090,9 +1003,8 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         d.pad2_ = 0;
         const uint32_t ri = (uint32_t)(w_rec + (unsigned)t);
         tp.recs[ri] = d;
-        tp.q_list[(size_t)(e.cls - 1) * tp.q_stride + qs4[e.cls - 1]] = ri;
-        qs4[e.cls - 1]++;
-        dpo += ((unsigned)e.xlen + (unsigned)e.ylen + 3u) & ~3u;
+        tp.q_list[(size_t)e.cls * tp.q_stride + qs4[e.cls]] = ri;
+        qs4[e.cls]++;
       }
       ReadMemo m2 = memo;
       m2.base[memo.n_rounds] = (uint32_t)w_rec;
@@ -1116,20 +1028,12 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         const int nb = lead5 + a.nops + 5 * (int)a.n_y + trail5;
         const bool exonic = a.aln_type == THM_ALN_EXONIC;
         const int tnb = exonic ? lead5 + a.nops + trail5 : 0;
-        PathView pv;
-        pv.nl = a.nl;
-        pv.len = a.len;
-        pv.nops = a.nops;
-        pv.l_sp = a.l_sp;
-        pv.r_sp = a.r_sp;
-        pv.l_ops = a.l_rec >= 0 ? tp.dp_ops + tp.recs[a.l_rec].ops_off : nullptr;
-        pv.r_ops = a.r_rec >= 0 ? tp.dp_ops + tp.recs[a.r_rec].ops_off : nullptr;
-        emit_stream(p.cand_ops + my_off, nb, pv, lead, trail, a.rev != 0, (int)a.n_y, a.mk_k, a.ycl);
+        emit_stream(p.cand_ops + my_off, nb, a.ed, (int)a.n_ed, lead, trail, a.rev != 0, (int)a.n_y, a.mk_k, a.ycl);
         const unsigned long long goff = my_off;
         my_off += ((unsigned)nb + 3u) & ~3u;
         unsigned long long toff = 0;
         if (exonic) {
-          emit_stream(p.cand_ops + my_off, tnb, pv, lead, trail, false, 0, a.mk_k, a.ycl);
+          emit_stream(p.cand_ops + my_off, tnb, a.ed, (int)a.n_ed, lead, trail, false, 0, a.mk_k, a.ycl);
           toff = my_off;
           my_off += ((unsigned)tnb + 3u) & ~3u;
         }
@@ -1197,7 +1101,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
       if (tp.stats) {
         const unsigned long long mk = __ballot(mine && !done && !sleep);
         if (lane == 0 && mk) atomicAdd(&s_stats[0], (unsigned)__popcll(mk));
-        for (int w = 1; w < 8; w++) {
+        for (int w = 1; w < 16; w++) {
           const unsigned long long m2 = __ballot(mine && !done && !sleep && why == w);
           if (lane == 0 && m2) atomicAdd(&s_stats[w], (unsigned)__popcll(m2));
         }
@@ -1209,7 +1113,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
     const unsigned long long v = s_cnt[threadIdx.x];
     if (v) p.wave_counters[(size_t)blockIdx.x * THM_N_COUNTERS + threadIdx.x] += v;  // the row is this workgroup's in every round
   }
-  if (tp.stats && threadIdx.x < 8 && s_stats[threadIdx.x]) atomicAdd(&tp.stats[threadIdx.x], (unsigned long long)s_stats[threadIdx.x]);
+  if (tp.stats && threadIdx.x < 16 && s_stats[threadIdx.x]) atomicAdd(&tp.stats[threadIdx.x], (unsigned long long)s_stats[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1267,9 +1171,9 @@ __device__ __forceinline__ void dp_class(const DpParams& p, uint8_t* xs, uint8_t
   const int lane = lane_id();
   // (the cursor may have run past the list when the request pools were exhausted: those reads went to the wave-per-read
   // kernel and their slots, as far as they exist, hold 0xFFFFFFFF)
-  const unsigned long long q0 = min(p.q_done[CPL - 1], (unsigned long long)p.q_stride), q1 = min(p.q_cur[CPL - 1], (unsigned long long)p.q_stride);
+  const unsigned long long q0 = min(p.q_done[CPL], (unsigned long long)p.q_stride), q1 = min(p.q_cur[CPL], (unsigned long long)p.q_stride);
   if (q0 >= q1) return;
-  const uint32_t* list = p.q_list + (size_t)(CPL - 1) * p.q_stride;
+  const uint32_t* list = p.q_list + (size_t)CPL * p.q_stride;
   // Requests are handed out by position, wave w takes w, w + n_waves, ...: a request is one extension of a few dozen
   // columns, a wave gets dozens of them, so the shares even out -- and there is no work counter (one hot word serves
   // about 88 M returning atomics per second: 175 000 chunks of two took 2 ms, whatever the occupancy).
@@ -1301,21 +1205,273 @@ __device__ __forceinline__ void dp_class(const DpParams& p, uint8_t* xs, uint8_t
       fault |= nops < 0 ? 2 : 4;
       nops = 0;
     }
-    uint8_t* out = p.dp_ops + rq.ops_off;
+    // The result's ops are Match but for a few: those few go into the record, (index << 2 | kind), in the traceback's
+    // order; the control kernel rebuilds the op list from them.
+    uint16_t* eds = (uint16_t*)(opsb + ops_cap - 16);  // (the ops end at least 128 bytes before)
+    int n_ed = 0;
 #pragma unroll 1
-    for (int t = lane; t < nops; t += 64) out[t] = opsb[t];
+    for (int t0 = 0; t0 < nops; t0 += 64) {
+      const int t = t0 + lane;
+      const int v = t < nops ? (int)opsb[t] : 0;
+      const unsigned long long m = __ballot(v != 0);
+      if (v) {
+        const int at = n_ed + __popcll(m & ((1ull << lane) - 1ull));
+        if (at < DP_MAX_EDITS) eds[at] = (uint16_t)((t << 2) | v);
+      }
+      n_ed += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    DpRec* d = p.recs + ri;
+    if (lane < DP_MAX_EDITS && lane < n_ed && n_ed <= DP_MAX_EDITS) ((uint16_t*)d)[lane] = eds[lane];
     if (lane == 0) {
-      DpRec* d = p.recs + ri;
       d->score = r.score;
       d->xend = (uint16_t)r.xend;
       d->yend = (uint16_t)r.yend;
       d->nops = (uint16_t)nops;
+      d->n_edits = n_ed <= DP_MAX_EDITS ? (uint16_t)n_ed : (uint16_t)0xFFFF;
       d->cells = r.cells;  // counted by the control kernel when (and if) the read is finished with this result
       d->cols = r.cols;
       d->done = 1;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Thread-per-problem DP kernel (class 0): SwgExtend::extend + trace (reference src/swg.rs:31-207)
+// statement by statement, one problem per THREAD, for the problems whose columns never hold more than DPT_SLOTS
+// cells: min(2 bw + 1, |x| + 1) <= 16.  That is every extension after a read's first accepted hit (the band is
+// L + range - score then: a few slots) and the short ends of reads -- the problems a wavefront-per-problem kernel does
+// worst at (a dozen live lanes of 64, ~50 vector and scalar instructions per column whatever the band).  Here the band
+// of a column is a thread's registers, a cell costs a dozen instructions, and a wavefront works on 64 problems.
+// The trace (2 bits per slot, one 32-bit word per column) is in LDS, laid out [column][thread]: conflict-free, and the
+// traceback -- a chain of dependent look-ups -- never leaves the CU.  x and y arrive eight symbols per load.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int DPT_THREADS = 128;
+// symbols t = 8 c .. 8 c + 7 of a sequence walked from p0 in direction dir (+1 / -1), symbol t in byte t - 8 c; only
+// symbols below len are touched
+__device__ __forceinline__ unsigned long long fetch8(const uint8_t* p0, int dir, int c, int len) {
+  // (one load for a chunk that holds a symbol below len: the reads, the text and the transcript sequences carry 16 bytes
+  // of padding in front and more behind, and the symbols at and beyond len are never looked at)
+  const int t0 = 8 * c;
+  if (t0 >= len) return 0ull;  // (a chunk fetched ahead of the last one)
+  unsigned long long v;
+  if (dir > 0) {
+    __builtin_memcpy(&v, p0 + t0, 8);
+  } else {
+    __builtin_memcpy(&v, p0 - t0 - 7, 8);
+    v = __builtin_bswap64(v);
+  }
+  return v;
+}
+}  // namespace
+
+__global__ __launch_bounds__(DPT_THREADS) void extend_dpt_kernel(DpParams p) {
+  constexpr int W = DPT_SLOTS;
+  constexpr int ge = GAP_EXTEND, go = GAP_OPEN;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_t[];
+  const unsigned tid = blockIdx.x * (unsigned)DPT_THREADS + threadIdx.x, n_threads = gridDim.x * (unsigned)DPT_THREADS;
+  uint32_t* const trace = (uint32_t*)smem_t + threadIdx.x;  // column j at trace[j * DPT_THREADS]
+  const unsigned long long q0 = min(p.q_done[0], (unsigned long long)p.q_stride), q1 = min(p.q_cur[0], (unsigned long long)p.q_stride);
+  int fault = 0;
+  for (unsigned long long qi = q0 + tid; qi < q1; qi += n_threads) {
+    const uint32_t ri = p.q_list[qi];
+    if (ri == 0xFFFFFFFFu) continue;
+    DpRec* const d = p.recs + ri;
+    const uint8_t* const x0 = d->x0;
+    const uint8_t* const y0 = d->y0;
+    const int xlen = d->xlen, ylen = d->ylen, bw = d->bw, xd = d->xd, dir = d->dir;
+    const int w = 2 * bw + 1;
+    if (min(w, xlen + 1) > W || (uint32_t)ylen + 1u > p.tcols || xlen == 0 || ylen == 0) {
+      fault |= 8;
+      continue;
+    }
+    // :62-71 leftmost column (its trace is all Ins: not stored)
+    int D[W + 1], C[W + 1];
+#pragma unroll
+    for (int b = 0; b <= W; b++) {
+      D[b] = b == 0 ? 0 : b * ge + go;
+      C[b] = b == 0 ? 0 : MIN_SCORE;
+    }
+    D[W] = C[W] = MIN_SCORE;  // (read by the last slot's look at its lower neighbour; never holds a cell)
+    // the x symbols of the band's rows: xw[b] = x[top + b - 1], top = 0 in phase 1 (slot b = row b)
+    int xw[W];
+    {
+      const unsigned long long c0 = fetch8(x0, dir, 0, xlen), c1 = fetch8(x0, dir, 1, xlen);
+#pragma unroll
+      for (int b = 0; b < W; b++) {
+        const int t = b - 1;  // x[t]
+        const int v = t < 8 ? (int)((c0 >> (8 * max(t, 0))) & 0xffull) : (int)((c1 >> (8 * (t - 8))) & 0xffull);
+        xw[b] = (b >= 1 && t < xlen) ? v : 0x100;  // 0x100: equals no symbol
+      }
+    }
+    int max_score = 0, max_i = 0, max_j = 0;
+    unsigned n_cells = 0, n_cols = 0;
+    // :75-113 band anchored at row 0
+    const int p1_end = min(bw, ylen);
+    const int rows = min(w, xlen + 1);
+    // y[j - 1] is the symbol of column j; eight of them per load, the next eight fetched while these are used
+    unsigned long long ych = fetch8(y0, dir, 0, ylen), ych_next = fetch8(y0, dir, 1, ylen);
+    auto y_at = [&](int t) -> int {  // symbols are asked for in ascending order
+      if ((t & 7) == 0 && t > 0) {
+        ych = ych_next;
+        ych_next = fetch8(y0, dir, (t >> 3) + 1, ylen);
+      }
+      return (int)((ych >> (8 * (t & 7))) & 0xffull);
+    };
+    int y_t = 0;  // next symbol to take
+    for (int j = 1; j <= p1_end; j++) {
+      const int yc = y_at(y_t++);
+      int band_max = MIN_SCORE, prev_D = MIN_SCORE, Rrun = MIN_SCORE, Dleft = MIN_SCORE;
+      uint32_t tw = 0;
+#pragma unroll
+      for (int b = 0; b < W; b++) {
+        if (b < rows) {
+          const int Cn = max(C[b] + ge, D[b] + ge + go);
+          const int Rn = b == 0 ? MIN_SCORE : max(Rrun + ge, Dleft + ge + go);
+          const bool eq = b > 0 && xw[b] == yc;
+          const int dg = b == 0 ? MIN_SCORE : prev_D + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+          prev_D = D[b];
+          const int sc = max(dg, max(Cn, Rn));
+          // triple_max (:226-240): diag (Match if the bases are equal, else Subst) > Del > Ins
+          const uint32_t op = sc == dg ? (eq ? (uint32_t)OPK_MATCH : (uint32_t)OPK_SUBST) : (sc == Cn ? (uint32_t)OPK_DEL : (uint32_t)OPK_INS);
+          D[b] = sc;
+          C[b] = Cn;
+          Rrun = Rn;
+          Dleft = sc;
+          tw |= op << (2 * b);
+          if (sc > max_score) {
+            max_score = sc;
+            max_i = b;
+            max_j = j;
+          }
+          band_max = max(band_max, sc);
+        }
+      }
+      trace[(size_t)j * DPT_THREADS] = tw;
+      n_cells += (unsigned)rows;
+      n_cols++;
+      if (band_max < max_score - xd) break;  // leaves ONLY this loop (:110-116); cannot fire with x_drop >= band_width
+    }
+    // :116-154 band slides down one row per column
+    if (y_t != bw && bw + 1 <= ylen) {  // phase 1 left early: cannot happen with x_drop >= band_width
+      fault |= 4;
+      continue;
+    }
+    // x[t] for the band's new last row: eight per load as well (t = W - 1, W, ...)
+    int x_t = W - 1;
+    unsigned long long xch = fetch8(x0, dir, x_t >> 3, xlen), xch_next = fetch8(x0, dir, (x_t >> 3) + 1, xlen);
+    for (int j = bw + 1; j <= ylen; j++) {
+      const int top = j - bw;
+      n_cols++;
+      if (top > xlen) break;  // empty row range: band_max = MIN -> X-drop
+      const int yc = y_at(y_t++);
+      // the band moved down a row: xw[b] = x[top + b - 1]; the new last slot holds x[top + W - 2]
+#pragma unroll
+      for (int b = 0; b < W - 1; b++) xw[b] = xw[b + 1];
+      {
+        if ((x_t & 7) == 0 && x_t > W - 1) {
+          xch = xch_next;
+          xch_next = fetch8(x0, dir, (x_t >> 3) + 1, xlen);
+        }
+        xw[W - 1] = x_t < xlen ? (int)((xch >> (8 * (x_t & 7))) & 0xffull) : 0x100;
+        x_t++;
+      }
+      const int nvalid = min(w, xlen + 1 - top);
+      int band_max = MIN_SCORE, Rrun = MIN_SCORE, Dleft = MIN_SCORE;
+      uint32_t tw = 0;
+#pragma unroll
+      for (int b = 0; b < W; b++) {
+        if (b < nvalid) {
+          const int Cn = (b >= w - 1) ? MIN_SCORE : max(C[b + 1] + ge, D[b + 1] + ge + go);
+          const int Rn = b == 0 ? MIN_SCORE : max(Rrun + ge, Dleft + ge + go);
+          const bool eq = xw[b] == yc;
+          const int dg = D[b] + (eq ? MATCH_SCORE : MISMATCH_SCORE);
+          const int sc = max(dg, max(Cn, Rn));
+          const uint32_t op = sc == dg ? (eq ? (uint32_t)OPK_MATCH : (uint32_t)OPK_SUBST) : (sc == Cn ? (uint32_t)OPK_DEL : (uint32_t)OPK_INS);
+          D[b] = sc;
+          C[b] = Cn;
+          Rrun = Rn;
+          Dleft = sc;
+          tw |= op << (2 * b);
+          if (sc > max_score) {
+            max_score = sc;
+            max_i = top + b;
+            max_j = j;
+          }
+          band_max = max(band_max, sc);
+        }
+      }
+      trace[(size_t)j * DPT_THREADS] = tw;
+      n_cells += (unsigned)nvalid;
+      if (band_max < max_score - xd) break;
+    }
+    // :170-207 traceback, the ops that are not Match as (index from the end cell << 2 | kind)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    unsigned long long ed_lo = 0, ed_hi = 0;
+    int n_ed = 0, n = 0;
+    {
+      int i = max_i, j = max_j, tj = -1;
+      uint32_t tw = 0;
+      int guard = xlen + ylen + 4;
+      while ((i > 0 || j > 0) && guard-- > 0) {
+        uint32_t op;
+        if (j == 0) {
+          op = (uint32_t)OPK_INS;  // column 0 is all Ins (:65,:70)
+        } else {
+          if (tj != j) {
+            tw = trace[(size_t)j * DPT_THREADS];
+            tj = j;
+          }
+          const int b = i - max(j - bw, 0);
+          if (b < 0 || b >= W) {
+            fault |= 2;
+            break;
+          }
+          op = (tw >> (2 * b)) & 3u;
+        }
+        if (op != (uint32_t)OPK_MATCH) {
+          const unsigned long long v = (unsigned long long)(((unsigned)n << 2) | op) & 0xffffull;
+          if (n_ed < 4)
+            ed_lo |= v << (16 * n_ed);
+          else if (n_ed < 8)
+            ed_hi |= v << (16 * (n_ed - 4));
+          n_ed++;
+        }
+        n++;
+        if (op <= (uint32_t)OPK_SUBST) {
+          if (i == 0 || j == 0) {
+            fault |= 2;
+            break;
+          }
+          i--;
+          j--;
+        } else if (op == (uint32_t)OPK_INS) {
+          if (i == 0) {
+            fault |= 2;
+            break;
+          }
+          i--;
+        } else {
+          j--;
+        }
+      }
+      if (guard <= 0) fault |= 2;
+    }
+    unsigned long long* d64 = (unsigned long long*)d;
+    d64[0] = ed_lo;
+    d64[1] = ed_hi;
+    d->score = max_score;
+    d->xend = (uint16_t)max_i;
+    d->yend = (uint16_t)max_j;
+    d->nops = (uint16_t)n;
+    d->n_edits = n_ed <= DP_MAX_EDITS ? (uint16_t)n_ed : (uint16_t)0xFFFF;
+    d->cells = n_cells;
+    d->cols = n_cols;
+    d->done = 1;
+  }
+  if (fault) atomicOr(p.fault, 2 | (fault << 4));
 }
 
 // CPLMAX: the widest band class of the run (the LDS trace is sized for it)
@@ -1377,6 +1533,18 @@ hipError_t launch_tpr_order(const ReadRecT<uint32_t>* recs, uint64_t n, uint32_t
 hipError_t launch_tpr_order(const ReadRecT<uint64_t>* recs, uint64_t n, uint32_t max_len, uint32_t max_hits, unsigned long long* bins, uint32_t* out,
                             unsigned long long* n_out, const int* fault_seed, hipStream_t s) {
   return launch_tpr_order_t(recs, n, max_len, max_hits, bins, out, n_out, fault_seed, s);
+}
+
+size_t extend_dpt_lds_bytes(uint32_t tcols) { return (size_t)dev::DPT_THREADS * tcols * 4; }
+hipError_t launch_extend_dpt(const DpParams& p, int n_blocks, hipStream_t s) {
+  if (n_blocks <= 0) return hipSuccess;
+  const size_t lds = extend_dpt_lds_bytes(p.tcols);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)dev::extend_dpt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(dev::extend_dpt_kernel, dim3(n_blocks), dim3(dev::DPT_THREADS), lds, s, p);
+  return hipGetLastError();
 }
 
 hipError_t launch_extend_dp(const DpParams& p, int cpl_max, int n_blocks, hipStream_t s) {

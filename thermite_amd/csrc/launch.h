@@ -257,17 +257,97 @@ inline bool team_fits_lds(size_t lds4) { return lds4 / 4 * TEAM_WAVES + TEAM_STA
 // team = true: the workgroup-per-read variant for reads with very many hits (cpl 1 or 2 only; TEAM_WAVES waves per workgroup)
 hipError_t launch_extend(const ExtendParamsT<uint32_t>& p, int cpl, int n_blocks, hipStream_t s, bool team = false);
 hipError_t launch_extend(const ExtendParamsT<uint64_t>& p, int cpl, int n_blocks, hipStream_t s, bool team = false);
+// ---- hit summaries (kernels_hit.hip): the part of align_seed_hit that does not depend on the state align_read carries
+// from hit to hit (band, X-drop, best score), computed once per hit by a group of eight lanes ----
+// What an extension looks like before any DP (swg_device.h::swg_one_mismatch_shortcut and the bound argument in
+// kernels_tpr.hip).  y has min(A, |x| + bw + 1) symbols; only A is kept, the rest is the reader's state.
+enum : uint16_t {
+  SK_EMPTY = 0,     // |x| == 0 or no y: score 0, nothing aligned (src/swg.rs:39-55)
+  SK_SINGLE = 1,    // one base that mismatches: score 0, nothing aligned
+  SK_SHORTCUT = 2,  // first pair mismatches, the rest of x matches exactly, x not one repeated base, A >= |x|: Subst, Match x (|x| - 1),
+                    // score |x| - 2 -- provided x_drop >= 1, which the reader checks
+  SK_UNK_DEL = 3,   // needs a DP; score <= |x| - 1 (x == y[1 .. |x| + 1): one leading deletion)
+  SK_UNK = 4,       // needs a DP; score <= max(|x| - 2, 0) (first pair mismatches)
+  SK_UNK_EQ = 5     // needs a DP; no bound below |x| (first pair matches: not a maximal seed)
+};
+struct HitSide {
+  uint16_t kind;
+  uint16_t eq;  // transcript targets: leading y symbols equal to the genome window's side (0: other x, or none), up to min(A, A_genome, |x| + bw0 + 1)
+  uint32_t A;   // symbols of the target available to the extension (clamped to 2^32 - 1)
+};
+// one transcript target of a hit after lift_mem_to_tx and extend_seed_match (src/txome.rs:82-103, src/aligner.rs:410-426)
+struct HitTgt {
+  uint32_t tx, ent;    // transcript, entry of the exon grid it was reached through
+  int32_t tr;          // the lifted, exactly extended seed: transcript position ...
+  uint16_t t_q, t_len; // ... read position, length
+  HitSide r, l;
+  uint32_t pos;        // position in exon_to_tx.find's yield order (ties go to the earlier target, src/aligner.rs:249)
+};
+constexpr int HIT_MAX_OPEN = 3;  // distinct targets of one hit that need a DP (more: the wave-per-read kernels take the read)
+constexpr int HIT_MAX_VAR = 4;   // targets whose window ends depend on the band (see win_*)
+enum : uint8_t { HF_COMPLEX = 1, HF_KNOWN = 2 };
+struct HitSum {
+  uint64_t hr;        // the hit: text position ...
+  uint32_t ref_id;    // ... its contig copy ...
+  uint16_t q, len;    // ... read position, length
+  HitSide gr, gl;     // genome window: right and left extension (A: symbols up to the contig's ends)
+  // Window bytes of the transcript targets (THM_CNT_WINDOW_BYTES counts [tr0 - (L + bw), tr0 + len0 + L + bw + 1) cut to
+  // the transcript, with the seed as lifted, before its exact extension).  A side of a window is never cut (counted in
+  // win_nl / win_nr: L + bw resp. L + bw + 1 symbols), always cut (its size is in win_fixed), or cut for some bands
+  // (win_var: the symbols available, left sides first: win_nvl of them, then win_nvr right sides).
+  uint32_t win_fixed;  // sum over the targets of len0 + the always-cut sides
+  uint8_t win_nl, win_nr, win_nvl, win_nvr;
+  uint16_t win_var[HIT_MAX_VAR];
+  uint8_t n_tgt;       // targets evaluated (up to and including the first that is exact): two extend() calls each
+  uint8_t n_open;
+  uint8_t flags;       // HF_COMPLEX: beyond this path's capacities (why in `why`); HF_KNOWN: `known` is set
+  uint8_t why;
+  HitTgt known;        // the best target whose two extensions are known in closed form (first of the best, in yield order)
+  HitTgt open[HIT_MAX_OPEN];  // the targets that need a DP, in yield order, without repetitions of an earlier one
+  uint32_t pad_;
+};
+static_assert(sizeof(HitSide) == 8 && sizeof(HitTgt) == 36 && sizeof(HitSum) == 200, "hit summary layout");
+// (read, q, len, hr) of every hit of the reads this path takes, at the hit's slot = its read's cand_off + ordinal
+struct HitHdr {
+  uint64_t hr;
+  uint32_t read;  // 0xFFFFFFFF: not a hit of this path
+  uint16_t q, len;
+};
+template <class C>
+struct HitParamsT {
+  DeviceIndexT<C> ix;
+  ReadBatch reads;
+  thm_align_opts opts;
+  const SmemT<C>* smems;
+  const ReadRecT<C>* read_recs;
+  uint32_t max_read_len, max_hits;  // the reads of this path: fast class, fewer than max_hits hits
+  HitHdr* hdr;                      // [slots]
+  HitSum* sums;                     // [slots]
+  const uint64_t* total_hits;       // slots in use (the last element of the scan of the hit counts)
+  uint64_t slot_cap;
+  const int* fault_seed;
+};
+hipError_t launch_hit_expand(const HitParamsT<uint32_t>& p, hipStream_t s);
+hipError_t launch_hit_expand(const HitParamsT<uint64_t>& p, hipStream_t s);
+hipError_t launch_hit_summaries(const HitParamsT<uint32_t>& p, int n_blocks, hipStream_t s);
+hipError_t launch_hit_summaries(const HitParamsT<uint64_t>& p, int n_blocks, hipStream_t s);
+
 // ---- extension problems as the unit of wavefront work (kernels_tpr.hip) ----
 // One SwgExtend::extend call that needs a DP: written by the control kernel (thread per read), computed by the DP
 // kernel (wave per record), read back by the control kernel in the next round.
+constexpr int DP_MAX_EDITS = 8;  // ops other than Match one result may carry (more: the wave-per-read kernels take the read)
 struct DpRec {
-  const uint8_t* x0;  // x[t] = x0[t * dir]: the read as the extension walks it
-  const uint8_t* y0;  // y[t] = y0[t * dir]: the target (text or transcript sequence)
-  uint64_t ops_off;   // room for xlen + ylen op bytes in the DP op pool; the DP kernel leaves the ops in traceback order
+  // request: x[t] = x0[t * dir], the read as the extension walks it; y[t] = y0[t * dir], the target (text or transcript
+  // sequence).  After the DP the same 16 bytes hold the result's ops that are not Match: n_edits entries of
+  // (index << 2 | op kind), index counting from the end cell back to the seed (the traceback's order), ascending.
+  const uint8_t* x0;
+  const uint8_t* y0;
+  uint64_t pad0_;
   uint16_t xlen, ylen, bw, xd;
   int8_t dir;         // +1: right extension, -1: left extension
-  uint8_t cls;        // band slots per lane the problem needs: ceil(min(2 bw + 1, xlen + 1) / 64), 1..4
-  uint16_t pad_;
+  uint8_t cls;        // 0: at most DPT_SLOTS band slots hold cells (thread-per-problem kernel); else the band slots per lane the
+                      // wave-per-problem kernel needs, ceil(min(2 bw + 1, xlen + 1) / 64) = 1..4
+  uint16_t n_edits;   // result: ops other than Match (0xFFFF: more than DP_MAX_EDITS)
   uint32_t read;      // (diagnostics)
   // result
   int32_t score;
@@ -277,10 +357,12 @@ struct DpRec {
   uint32_t pad2_;
 };
 static_assert(sizeof(DpRec) == 64, "DpRec layout");
+constexpr int DPT_SLOTS = 16;      // band slots of the thread-per-problem DP kernel (registers of one thread)
+constexpr int DP_NQ = 5;           // request queues: class 0 (narrow) and band classes 1..4
 constexpr int TPR_MAX_ROUNDS = 8;  // rounds of requests one read may take (then: the wave-per-read kernel)
 // Reads with this many seed hits and more stay with the workgroup-per-read / wave-per-read kernels: the control kernel
 // replays a read's hits in one thread, and a thread with thousands of hits would be the tail of its launch.
-constexpr unsigned TPR_MAX_HITS = 8;
+constexpr unsigned TPR_MAX_HITS = 32;
 // The records of a read, by round: round k asked for the extension problems of the hits from first_hit[k] on (one
 // hit, or all the remaining ones), in the order the replay meets them, under the band and X-drop in force there:
 // records base[k] .. base[k] + cnt[k].
@@ -299,12 +381,9 @@ struct TprParamsT {
   DpRec* recs;
   uint64_t rec_cap;
   unsigned long long* rec_cursor;
-  uint8_t* dp_ops;
-  uint64_t dp_ops_cap;
-  unsigned long long* dp_ops_cursor;
-  uint32_t* q_list;            // [4][q_stride] record indices by band class, appended to over the rounds
+  uint32_t* q_list;            // [DP_NQ][q_stride] record indices by class, appended to over the rounds
   uint64_t q_stride;
-  unsigned long long* q_cur;   // [4] ends of the lists
+  unsigned long long* q_cur;   // [DP_NQ] ends of the lists
   const uint32_t* act_in;      // reads of this round (round 0: all reads, no list)
   const unsigned long long* n_act_in;
   uint32_t* act_out;           // reads that wait for results: the next round's list
@@ -314,23 +393,28 @@ struct TprParamsT {
   unsigned long long* team;    // ... or, with TEAM_MIN_HITS hits and more, to the workgroup-per-read kernel's (null: none runs)
   unsigned long long* team_count;
   uint32_t max_hits;           // reads with this many hits and more are not this path's (TPR_MAX_HITS)
+  uint32_t dpt_cols;           // columns the thread-per-problem DP kernel's trace holds (DpParams::tcols)
+  const HitSum* sums;          // hit summaries (kernels_hit.hip), by hit slot
   uint32_t round;
   uint32_t last_round;         // 1: no DP launch follows; a read that still needs results goes to the wave-per-read kernel
-  unsigned long long* stats;   // 8 words (may be null): [0] reads left to the wave-per-read kernel, [1..7] why
+  unsigned long long* stats;   // 16 words (may be null): [0] reads left to the wave-per-read kernel, [1..15] why
 };
 struct DpParams {
   DpRec* recs;
-  uint8_t* dp_ops;
   const uint32_t* q_list;
   uint64_t q_stride;
-  const unsigned long long* q_cur;   // [4]
-  const unsigned long long* q_done;  // [4] ends of the lists as of the previous round
+  const unsigned long long* q_cur;   // [DP_NQ]
+  const unsigned long long* q_done;  // [DP_NQ] ends of the lists as of the previous round
   unsigned int* work;                // work counters of this launch, one per band class, 64 bytes apart (zeroed before the run)
   int* fault;
   uint32_t x_cap, y_cap;             // per-wave LDS bytes for x and y (multiples of 16, 64 bytes of slack each)
   unsigned long long* trace_scratch; // problems of more than 64 band slots: [waves of the launch][trace_per_wave] u64
   uint64_t trace_per_wave;
+  uint32_t tcols;                    // thread-per-problem kernel: columns its LDS trace holds (a class-0 problem has at most
+                                     // max(L + DPT_SLOTS / 2 + 1, DPT_SLOTS + bw) columns)
 };
+size_t extend_dpt_lds_bytes(uint32_t tcols);  // per workgroup
+hipError_t launch_extend_dpt(const DpParams& p, int n_blocks, hipStream_t s);  // class 0: one problem per THREAD
 size_t extend_dp_lds_bytes(uint32_t x_cap, uint32_t y_cap);  // per workgroup (4 waves)
 size_t extend_dp_trace_bytes(uint32_t y_cap, int cpl_max);   // per wave
 hipError_t launch_extend_ctl(const ExtendParamsT<uint32_t>& p, const TprParamsT<uint32_t>& tp, int n_blocks, hipStream_t s);
@@ -343,8 +427,8 @@ hipError_t launch_tpr_order(const ReadRecT<uint64_t>* recs, uint64_t n, uint32_t
                             unsigned long long* n_out, const int* fault_seed, hipStream_t s);
 constexpr int TPR_CTL_BLOCKS_PER_CU = 4, TPR_DP_BLOCKS_PER_CU = 8;
 // layout of the small control block of a run (u64 words; zeroed before the run)
-enum { TPRC_REC_CUR = 0, TPRC_DPO_CUR = 1, TPRC_Q_CUR = 2, TPRC_Q_DONE = 6, TPRC_N_ACT = 10 /* [TPR_MAX_ROUNDS + 2] */, TPRC_STATS = 24 /* [8] */, TPRC_BAIL_CNT = 23,
-       TPRC_BINS = 32 /* [128]: reads per hit count, cursors (tpr_order_kernel) */,
+enum { TPRC_REC_CUR = 0, TPRC_Q_CUR = 2 /* [DP_NQ] */, TPRC_Q_DONE = 7 /* [DP_NQ] */, TPRC_N_ACT = 12 /* [TPR_MAX_ROUNDS + 2] */, TPRC_STATS = 24 /* [16] */, TPRC_BAIL_CNT = 23,
+       TPRC_BINS = 40 /* [128]: reads per hit count, cursors (tpr_order_kernel) */,
        TPRC_WORK_BYTES = 2048 /* u32 work counters, 64 bytes apart: [round][class] */ };
 constexpr size_t TPRC_BYTES = TPRC_WORK_BYTES + (size_t)(TPR_MAX_ROUNDS + 1) * 4 * 64;
 

@@ -74,8 +74,10 @@ int enqueue_seed_t(thm_aligner* a, uint32_t min_seed_len) {
   HIPCHK(a, a->s_smems.ensure(a->smem_cap * sizeof(SmemT<C>)));
   if (!a->dbg_smem_cap) a->smem_cap = std::max<uint64_t>(a->smem_cap, a->s_smems.cap / sizeof(SmemT<C>));
   // to_ascii_uppercase (src/aligner.rs:125) + sanitising, once per run for both kernels
-  HIPCHK(a, a->r_san.ensure(a->n_bases + 256));
-  HIPCHK(a, launch_sanitize(a->r_bases.as<uint8_t>(), a->r_san.as<uint8_t>(), a->n_bases, a->n_bases + 128, s));
+  // (16 bytes in front: a left extension is read in whole 8-byte words that may begin a few bytes before the first read)
+  HIPCHK(a, a->r_san.ensure(a->n_bases + 256 + 16));
+  HIPCHK(a, hipMemsetAsync(a->r_san.p, 0, 16, s));
+  HIPCHK(a, launch_sanitize(a->r_bases.as<uint8_t>(), a->r_san.as<uint8_t>() + 16, a->n_bases, a->n_bases + 128, s));
   // length classes of the seed stage (launch.h): short reads take the byte-per-position paths
   uint64_t n_long = 0;
   uint32_t max_short = 0, max_long = 0;
@@ -109,7 +111,7 @@ int enqueue_seed_t(thm_aligner* a, uint32_t min_seed_len) {
   const int n_blocks = blocks_for(a, n, std::min(seed_select_lds_bytes(std::max(max_short, 1u)), SEED_SELECT_LDS_LIMIT));
   SeedParamsT<C> sp;
   sp.ix = dev_view<C>(a);
-  sp.reads.bases = a->r_san.as<uint8_t>();
+  sp.reads.bases = a->r_san.as<uint8_t>() + 16;
   sp.reads.offsets = a->r_offsets.as<uint64_t>();
   sp.reads.n_reads = n;
   sp.min_seed_len = min_seed_len;
@@ -192,7 +194,7 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   hipStream_t s = a->stream;
   ExtendParamsT<C> ep;
   ep.ix = dev_view<C>(a);
-  ep.reads.bases = a->r_san.as<uint8_t>();
+  ep.reads.bases = a->r_san.as<uint8_t>() + 16;
   ep.reads.offsets = a->r_offsets.as<uint64_t>();
   ep.reads.n_reads = n;
   ep.opts = a->opts;
@@ -278,6 +280,12 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   const uint32_t dp_x_cap = (cls.fast_len + 64u + 15u) & ~15u, dp_y_cap = (cls.fast_len + cls.fast_bw + 2u + 64u + 15u) & ~15u;
   const int dp_per_cu = (int)std::max<size_t>(1, std::min<size_t>(TPR_DP_BLOCKS_PER_CU, EXTEND_LDS_LIMIT / std::max<size_t>(1, extend_dp_lds_bytes(dp_x_cap, dp_y_cap))));
   const int dp_blocks = tpr ? a->n_cu * dp_per_cu : 0;
+  // thread-per-problem kernel (class 0: at most DPT_SLOTS band slots hold cells): columns of its LDS trace -- such a problem
+  // has a band of at most +-7 (|y| <= |x| + 8) or an x of at most 15 symbols (|y| <= 16 + bw); workgroups that fit a CU
+  // (at most 128 columns, 64 KiB of LDS per workgroup: longer ones are the wave-per-problem kernel's)
+  const uint32_t dpt_tcols = std::min<uint32_t>(std::min<uint32_t>(dp_y_cap, 128u), std::max<uint32_t>(cls.fast_len + DPT_SLOTS / 2 + 2, DPT_SLOTS + cls.fast_bw + 2));
+  const int dpt_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, EXTEND_LDS_LIMIT / std::max<size_t>(1, extend_dpt_lds_bytes(dpt_tcols))));
+  const int dpt_blocks = tpr ? a->n_cu * dpt_per_cu : 0;
   // rows: [main | team | slow | control kernel's workgroups | the wave-per-read launch for what the control kernel leaves]
   const int bail_blocks = tpr ? std::min(ext_blocks, a->n_cu) : 0;
   const uint64_t tpr_rows = (uint64_t)ctl_blocks + (uint64_t)bail_blocks * 4;
@@ -288,11 +296,9 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   ep.skip_scan = 0;
   if (tpr) {
     const uint64_t rec_cap = std::min<uint64_t>(4 * n + 65536, 64ull << 20);
-    const uint64_t dpo_cap = rec_cap * 192;
     HIPCHK(a, a->t_memos.ensure(n * sizeof(ReadMemo) + 64));
     HIPCHK(a, a->t_recs.ensure(rec_cap * sizeof(DpRec) + 64));
-    HIPCHK(a, a->t_dpops.ensure(dpo_cap + 64));
-    HIPCHK(a, a->t_qlist.ensure(4 * rec_cap * 4 + 64));
+    HIPCHK(a, a->t_qlist.ensure((size_t)DP_NQ * rec_cap * 4 + 64));
     HIPCHK(a, a->t_act[0].ensure(n * 4 + 64));
     HIPCHK(a, a->t_act[1].ensure(n * 4 + 64));
     HIPCHK(a, a->t_bail.ensure((n + 1) * 8));
@@ -301,6 +307,63 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
     HIPCHK(a, a->t_ctl.ensure(TPRC_BYTES));
     HIPCHK(a, hipMemsetAsync(a->t_ctl.p, 0, TPRC_BYTES, s));
     unsigned long long* ctl = a->t_ctl.as<unsigned long long>();
+    TprParamsT<C> tq;
+    tq.recs_rw = a->e_recs.as<ReadRecT<C>>();
+    tq.memos = a->t_memos.as<ReadMemo>();
+    tq.recs = a->t_recs.as<DpRec>();
+    tq.rec_cap = rec_cap;
+    tq.rec_cursor = ctl + TPRC_REC_CUR;
+    tq.q_list = a->t_qlist.as<uint32_t>();
+    tq.q_stride = rec_cap;
+    tq.q_cur = ctl + TPRC_Q_CUR;
+    tq.bail = a->t_bail.as<unsigned long long>();
+    tq.bail_count = ctl + TPRC_BAIL_CNT;
+    tq.team = nullptr;  // (the team kernel is running already; a read of this path has fewer hits than it takes anyway)
+    tq.team_count = nullptr;
+    tq.max_hits = TPR_MAX_HITS;
+    tq.dpt_cols = dpt_tcols;
+    tq.stats = ctl + TPRC_STATS;
+    ExtendParamsT<C> zp = ep;
+    zp.wave_counters = ep.wave_counters + (main_rows + team_rows + slow_waves) * THM_N_COUNTERS;
+    DpParams dq;
+    dq.recs = tq.recs;
+    dq.q_list = tq.q_list;
+    dq.q_stride = tq.q_stride;
+    dq.q_cur = ctl + TPRC_Q_CUR;
+    dq.q_done = ctl + TPRC_Q_DONE;
+    dq.fault = ep.fault;
+    dq.x_cap = dp_x_cap;
+    dq.y_cap = dp_y_cap;
+    {
+      const size_t tb = extend_dp_trace_bytes(dp_y_cap, cpl);
+      HIPCHK(a, a->t_trace.ensure((size_t)dp_blocks * 4 * tb + 64));
+      dq.trace_scratch = a->t_trace.as<unsigned long long>();
+      dq.trace_per_wave = tb / 8;
+      dq.tcols = dpt_tcols;
+    }
+    // hit summaries: everything about a hit that does not depend on the state align_read carries, all hits side by side
+    {
+      const uint64_t slot_cap = a->cand_cap;
+      HIPCHK(a, a->t_hdr.ensure(slot_cap * sizeof(HitHdr) + 64));
+      HIPCHK(a, a->t_sums.ensure(slot_cap * sizeof(HitSum) + 64));
+      HIPCHK(a, hipMemsetAsync(a->t_hdr.p, 0xFF, slot_cap * sizeof(HitHdr), s));
+      HitParamsT<C> hq;
+      hq.ix = ep.ix;
+      hq.reads = ep.reads;
+      hq.opts = ep.opts;
+      hq.smems = ep.smems;
+      hq.read_recs = ep.read_recs;
+      hq.max_read_len = cls.fast_len;
+      hq.max_hits = TPR_MAX_HITS;
+      hq.hdr = a->t_hdr.as<HitHdr>();
+      hq.sums = a->t_sums.as<HitSum>();
+      hq.total_hits = a->s_cand_off.as<uint64_t>() + n;
+      hq.slot_cap = slot_cap;
+      hq.fault_seed = a->d_fault.as<int>();
+      HIPCHK(a, launch_hit_expand(hq, s));
+      HIPCHK(a, launch_hit_summaries(hq, a->n_cu * 12, s));
+      tq.sums = a->t_sums.as<HitSum>();
+    }
     // The reads with HEAVY_HITS hits and more (the lists of plan_kernel) are the wave-per-read / workgroup-per-read
     // kernels': they run BESIDE the rounds below, on their own streams.
     {
@@ -317,45 +380,9 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
         tp.trace_scratch = ep.trace_scratch + main_trace_waves * trace_per_wave / 8;
         HIPCHK(a, launch_extend(tp, cpl, a->n_cu, a->stream2, true));
       }
-      HIPCHK(a, launch_extend(hp, cpl, ext_blocks, a->stream3));
+      HIPCHK(a, launch_extend(hp, cpl, std::min(ext_blocks, a->n_cu), a->stream3));  // (a few thousand reads: one workgroup per CU leaves the machine to the rounds)
       HIPCHK(a, hipEventRecord(a->ev_join, a->stream2));
       HIPCHK(a, hipEventRecord(a->ev_join3, a->stream3));
-    }
-    TprParamsT<C> tq;
-    tq.recs_rw = a->e_recs.as<ReadRecT<C>>();
-    tq.memos = a->t_memos.as<ReadMemo>();
-    tq.recs = a->t_recs.as<DpRec>();
-    tq.rec_cap = rec_cap;
-    tq.rec_cursor = ctl + TPRC_REC_CUR;
-    tq.dp_ops = a->t_dpops.as<uint8_t>();
-    tq.dp_ops_cap = dpo_cap;
-    tq.dp_ops_cursor = ctl + TPRC_DPO_CUR;
-    tq.q_list = a->t_qlist.as<uint32_t>();
-    tq.q_stride = rec_cap;
-    tq.q_cur = ctl + TPRC_Q_CUR;
-    tq.bail = a->t_bail.as<unsigned long long>();
-    tq.bail_count = ctl + TPRC_BAIL_CNT;
-    tq.team = nullptr;  // (the team kernel is running already; a read of this path has fewer hits than it takes anyway)
-    tq.team_count = nullptr;
-    tq.max_hits = TPR_MAX_HITS;
-    tq.stats = ctl + TPRC_STATS;
-    ExtendParamsT<C> zp = ep;
-    zp.wave_counters = ep.wave_counters + (main_rows + team_rows + slow_waves) * THM_N_COUNTERS;
-    DpParams dq;
-    dq.recs = tq.recs;
-    dq.dp_ops = tq.dp_ops;
-    dq.q_list = tq.q_list;
-    dq.q_stride = tq.q_stride;
-    dq.q_cur = ctl + TPRC_Q_CUR;
-    dq.q_done = ctl + TPRC_Q_DONE;
-    dq.fault = ep.fault;
-    dq.x_cap = dp_x_cap;
-    dq.y_cap = dp_y_cap;
-    {
-      const size_t tb = extend_dp_trace_bytes(dp_y_cap, cpl);
-      HIPCHK(a, a->t_trace.ensure((size_t)dp_blocks * 4 * tb + 64));
-      dq.trace_scratch = a->t_trace.as<unsigned long long>();
-      dq.trace_per_wave = tb / 8;
     }
     // round 0's list: the reads of this path by descending hit count
     HIPCHK(a, launch_tpr_order(a->e_recs.as<ReadRecT<C>>(), n, cls.fast_len, TPR_MAX_HITS, ctl + TPRC_BINS, a->t_act[0].as<uint32_t>(), ctl + TPRC_N_ACT,
@@ -371,8 +398,15 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
       HIPCHK(a, launch_extend_ctl(zp, tq, ctl_blocks, s));
       if (r == n_rounds) break;
       dq.work = (unsigned int*)((uint8_t*)a->t_ctl.p + TPRC_WORK_BYTES + (size_t)r * 4 * 64);
+      // the two DP kernels of a round side by side: the thread-per-problem one has a few hundred wavefronts of long
+      // serial work (one column after the other, per thread), the wave-per-problem one fills the machine
+      HIPCHK(a, hipEventRecord(a->ev_dpt_fork, s));
+      HIPCHK(a, hipStreamWaitEvent(a->stream4, a->ev_dpt_fork, 0));
+      HIPCHK(a, launch_extend_dpt(dq, dpt_blocks, a->stream4));
+      HIPCHK(a, hipEventRecord(a->ev_dpt_join, a->stream4));
       HIPCHK(a, launch_extend_dp(dq, cpl, dp_blocks, s));
-      HIPCHK(a, hipMemcpyAsync(ctl + TPRC_Q_DONE, ctl + TPRC_Q_CUR, 32, hipMemcpyDeviceToDevice, s));
+      HIPCHK(a, hipStreamWaitEvent(s, a->ev_dpt_join, 0));
+      HIPCHK(a, hipMemcpyAsync(ctl + TPRC_Q_DONE, ctl + TPRC_Q_CUR, DP_NQ * 8, hipMemcpyDeviceToDevice, s));
     }
     // what the control kernel left (capacities, rounds): one more wave-per-read launch over that list, behind the others
     HIPCHK(a, hipStreamWaitEvent(s, a->ev_join, 0));

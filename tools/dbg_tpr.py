@@ -15,7 +15,7 @@ for name, (b, o, opts) in {"long": (b2, o2, dict(min_seed_len=20, min_aln_score_
         a.debug_set_flags(tpr=True, rounds=rounds)
         try:
             g = a.align_batch(b, o)
-            print(name, rounds, "ok", len(g.alns), a.debug_tpr_stats().tolist(), flush=True)
+            print(name, rounds, "ok", len(g.alns), a.debug_tpr_stats()[:23].tolist(), flush=True)
         except Exception as e:
-            print(name, rounds, "FAIL", e, a.debug_tpr_stats().tolist(), flush=True)
+            print(name, rounds, "FAIL", e, a.debug_tpr_stats()[:23].tolist(), flush=True)
         a.close()

@@ -35,9 +35,10 @@ for name, opts in (("ci", capi.CI_OPTS), ("default", capi.DEFAULT_OPTS)):
         c[k] / (n * runs) for k in ("smems", "hits", "swg_calls", "dp_cols", "dp_cells", "alns", "window_bytes")), flush=True)
     if hasattr(a, "debug_tpr_stats"):
         es = a.debug_tpr_stats()
-        print("         problem-parallel path: %d DP requests (by band class %s), %d reads left to the wave-per-read kernel "
-              "(band %d grid %d lift %d capacity %d other %d), %d still waiting after the last round" % (
-                  es[8], es[10:14].tolist(), es[0], es[1], es[2], es[3], es[6], es[7], es[14]), flush=True)
+        names = {1: "band", 2: "grid", 3: "lift", 7: "other", 8: "rounds", 9: "candidates", 10: "edits", 11: "introns", 12: "pools", 13: "window", 14: "open"}
+        print("         problem-parallel path: %d DP requests (narrow %d, by band class %s), %d reads left to the wave-per-read kernel (%s), "
+              "%d still waiting after the last round" % (es[16], es[17], es[18:22].tolist(), es[0],
+                                                         " ".join("%s %d" % (names.get(k, str(k)), es[k]) for k in range(1, 16) if es[k]), es[22]), flush=True)
     pr = a.debug_prof()
     if pr.sum() > 0:
         names = ["setup", "stage", "dp", "traceback", "tree", "txprep", "lift", "emit", "final", "other"]
