@@ -81,16 +81,38 @@ def stream_reads(synth, tables, begin, end, L):
     return bases, (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)).astype("<u8")
 
 
+def csrc_hash():
+    """hash of the kernel and host sources the library is built from: ties a committed counter profile to a build"""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "thermite_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profile_entry(name, match):
-    """a committed profile summary (profiles/*.json) if it was taken on this workload, else None"""
+    """(summary, reason): a committed profile summary (profiles/*.json) if it was taken on this workload AND on the sources
+    this tree is built from (its csrc_hash), else (None, why not).  Counters are collected in separate rocprofv3 passes
+    (tools/profile_r03.sh): they cannot be measured inside the timed region, and a stale profile must not pass for one."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return None
+        return None, "no committed profile " + name
     try:
-        j = json.load(open(path))
+        js = json.load(open(path))
     except Exception:
-        return None
-    return j if all(j.get(k) == v for k, v in match.items()) else None
+        return None, "unreadable profile " + name
+    js = js if isinstance(js, list) else [js]  # one entry per workload
+    js = [e for e in js if all(e.get(k) == v for k, v in match.items())]
+    if not js:
+        return None, "no committed profile of this workload"
+    j = js[-1]
+    if j.get("csrc_hash") != csrc_hash():
+        return None, "committed profile was taken on other sources (csrc_hash %s, tree %s)" % (j.get("csrc_hash"), csrc_hash())
+    return j, None
 
 
 def main():
@@ -147,6 +169,7 @@ def main():
 
     # ---------------- reference + index ----------------
     t0 = time.time()
+    real_ref = None
     if args.workload == "chrM":
         from thermite_amd import refdata
 
@@ -154,6 +177,14 @@ def main():
         tables = refdata.load_reference(d + "/GRCh38-2020-A-chrM.fasta", d + "/GRCh38-2020-A-chrM.gtf")
         ref_len = int(tables["refs"][0]["len"])
         tag = "chrM"
+    elif os.environ.get("THM_CHR21_FASTA") and os.environ.get("THM_CHR21_GTF"):
+        # BASELINE configs[2] on the real inputs, when the caller has them (they are missing blobs in the reference checkout)
+        from thermite_amd import refdata
+
+        tables = refdata.load_reference(os.environ["THM_CHR21_FASTA"], os.environ["THM_CHR21_GTF"])
+        ref_len = int(tables["refs"][0]["len"])
+        tag = "user_%d_%d" % (ref_len, len(tables["text"]))
+        real_ref = os.path.basename(os.environ["THM_CHR21_FASTA"])
     else:
         ref_len = args.ref_len or synth.CHR21_LEN
         tables = synth.synth_reference(length=ref_len)
@@ -205,8 +236,10 @@ def main():
     # ---------------- timed region: exactly K steps ----------------
     K = args.steps
     stage_ms = {k: 0.0 for k in capi.TIMING_NAMES}
+    step_wall_ms, step_ext_ms = [], []  # per step: host wall time between completions, extend stage (HIP events)
     barrier()
     t0 = time.perf_counter()
+    t_prev = t0
     depth = max(1, min(args.inflight, NB))
     for i in range(K + depth - 1):
         if i < K:
@@ -215,7 +248,12 @@ def main():
         if j >= 0:
             a = aligners[j % NB]
             a.sync()  # stream sync + pool-overflow check; HIP-event stage times of this launch
-            for k, v in a.timings().items():
+            t_now = time.perf_counter()
+            step_wall_ms.append((t_now - t_prev) * 1e3)
+            t_prev = t_now
+            tm_ = a.timings()
+            step_ext_ms.append(tm_["extend"])
+            for k, v in tm_.items():
                 stage_ms[k] += v
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -252,17 +290,20 @@ def main():
     seed_bytes = n_r * L + n_r * max(L - k_seed + 1, 0) * 16 + 12 * per_launch("smems")
     ext_ms = stage_ms["extend"] / K
     achieved = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-    headline = (not strong and n_r == 500000 and args.workload == "chr21syn" and args.percent is None and L == 91
-                and not args.wide and ref_len == synth.CHR21_LEN)
-    match = {"reads_per_gpu": n_r, "ref_len": ref_len, "opts": args.opts} if headline else {"reads_per_gpu": -1}
-    tj = profile_entry("pmc_traffic.json", match)
-    sq = profile_entry("sq_counters.json", match)
+    profiled_kind = not strong and args.workload == "chr21syn" and real_ref is None
+    match = ({"reads_per_gpu": n_r, "ref_len": ref_len, "opts": args.opts, "read_len": L, "percent": args.percent, "wide": bool(args.wide)}
+             if profiled_kind else {"reads_per_gpu": -1})
+    tj, tj_why = profile_entry("pmc_traffic.json", match)
+    sq, sq_why = profile_entry("sq_counters.json", match)
+    spread = lambda v: {"min": round(float(np.min(v)), 4), "median": round(float(np.median(v)), 4), "max": round(float(np.max(v)), 4)}
     roofline = {
         "kernel": "extend_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": tj.get("extend_kernel_hbm_bytes_per_launch") if tj else None,
+        "traffic_source": ("profiles/pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on these sources (csrc_hash %s)" % tj.get("csrc_hash")) if tj else tj_why,
         "algorithmic_bytes_per_launch": int(ext_bytes), "kernel_ms": round(ext_ms, 4),
         "algorithmic_bytes_per_read_whole_path": round((ext_bytes + seed_bytes - n_r * L) / n_r, 1),
         "stage_ms": {k: round(v / K, 4) for k, v in stage_ms.items()},
+        "kernel_ms_per_step": spread(step_ext_ms),
         "note": "integer DP + random index probes: bound by HBM latency / VALU issue, not HBM bandwidth (SURVEY.md F7); see roofline_valu",
     }
     # the binding resource: vector-ALU issue.  busy = SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CU_CYCLES-equivalent from the committed
@@ -274,7 +315,7 @@ def main():
         "dp_cols_per_read": round(per_launch("dp_cols") / max(n_r, 1), 2),
         "valu_busy_frac": sq.get("extend_valu_busy_frac") if sq else None,
         "valu_insts_per_read": sq.get("extend_valu_insts_per_read") if sq else None,
-        "source": sq.get("source") if sq else None,
+        "source": sq.get("source") if sq else sq_why,
     }
 
     # ---------------- PCIe-inclusive rate (not `value`): upload + run + fetch of distinct batches ----------------
@@ -359,22 +400,26 @@ def main():
         }
 
     if rank == 0:
-        refdesc = "chr21-sized synthetic transcriptome" if args.workload == "chr21syn" else "GRCh38-2020-A chrM (real FASTA/GTF)"
+        refdesc = ("chr21-sized synthetic transcriptome" if args.workload == "chr21syn" else "GRCh38-2020-A chrM (real FASTA/GTF)") if real_ref is None \
+            else "user-supplied reference %s (THM_CHR21_FASTA / THM_CHR21_GTF)" % real_ref
         out = {
             "metric": "aligned reads/sec (%d bp)" % L, "value": round(value, 1), "unit": "reads/s", "n_gpus": world,
-            "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 4), "ms_per_step_spread": spread(step_wall_ms),
+            "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic" if real_ref is None else "synthetic reads from a user-supplied reference",
             "config": {
                 "workload": "%s vs %s (%d bp, %d tx), flags %s%s" % (
                     desc_reads, refdesc, ref_len, len(tables["txs"]),
                     "-k20 -s0 --intron-mode" if args.opts == "ci" else "defaults (-k20 -s0.66)",
                     "" if args.percent is None else " with -s%g" % args.percent),
-                "reads_per_gpu_per_step": reads_this_rank, "read_len": L, "ref_len": ref_len, "opts": args.opts,
+                "reads_per_gpu_per_step": reads_this_rank, "read_len": L, "ref_len": ref_len, "opts": args.opts, "percent": args.percent,
                 "coord_bytes": index.coord_bytes, "batches_in_flight": max(1, min(args.inflight, NB)),
                 "parallelism": "reads sharded over %d GPU(s), index replicated, 1 counter all-reduce" % world,
             },
             "roofline": roofline,
             "roofline_valu": roofline_valu,
+            "value_is": "batches resident in HBM before the timed region (the task's contract); value_e2e is the rate with host<->device "
+                        "transfers inside (BASELINE.md section 2 names both)",
             "value_e2e": value_e2e,
             "value_two_in_flight": value_two_in_flight,
             "cpu_baseline": cpu_baseline,

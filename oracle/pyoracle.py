@@ -120,6 +120,8 @@ def lib():
     L.orc_suffix_array_verify.argtypes = [vp, u64, vp]
     L.orc_index_create.restype = vp
     L.orc_index_create.argtypes = [vp, u64, vp, u32, vp, u32, vp, u64, vp, u64, vp, u32, vp, u32, vp, u32, u32]
+    L.orc_index_create64.restype = vp
+    L.orc_index_create64.argtypes = [vp, u64, vp, u32, vp, u32, vp, u64, vp, u64, vp, u32, vp, u32, vp, u32, u32, u32]
     L.orc_index_free.argtypes = [vp]
     L.orc_all_smems_batch.restype = vp
     L.orc_all_smems_batch.argtypes = [vp, vp, vp, u64, u64]
@@ -347,15 +349,24 @@ class Index:
     (verified in O(n)).
     """
 
-    def __init__(self, tables, sa=None, sa_sampling_rate=32, occ_sampling_rate=128):
+    def __init__(self, tables, sa=None, sa_sampling_rate=32, occ_sampling_rate=128, verify=True, keep_sa=True):
+        """A 64-bit suffix array (dtype u8) takes the usize-wide path of the index -- the reference's own width
+        (src/index.rs:103-111) and the only one for texts of 2^32 - 1 symbols and more.  verify=False / keep_sa=False:
+        for texts of billions of symbols (the check and the plain array cost 8 n bytes each)."""
         t = tables
         self.tables = t
-        sa_arr = None if sa is None else np.ascontiguousarray(sa, "<u4")
-        self.h = lib().orc_index_create(
-            _ptr(t["text"]), len(t["text"]), _ptr(t["refs"]), len(t["refs"]), _ptr(t["txs"]), len(t["txs"]),
-            _ptr(t["exons"]), len(t["exons"]), _ptr(t["tx_seq"]), len(t["tx_seq"]), _ptr(t["genes"]), len(t["genes"]),
-            _ptr(t["name_rank"]), len(t["name_rank"]), _ptr(sa_arr), sa_sampling_rate, occ_sampling_rate,
-        )
+        wide = sa is not None and np.asarray(sa).dtype.itemsize == 8
+        args = (_ptr(t["text"]), len(t["text"]), _ptr(t["refs"]), len(t["refs"]), _ptr(t["txs"]), len(t["txs"]),
+                _ptr(t["exons"]), len(t["exons"]), _ptr(t["tx_seq"]), len(t["tx_seq"]), _ptr(t["genes"]), len(t["genes"]),
+                _ptr(t["name_rank"]), len(t["name_rank"]))
+        if wide:
+            sa_arr = np.ascontiguousarray(sa, "<u8")
+            self.h = lib().orc_index_create64(*args, _ptr(sa_arr), sa_sampling_rate, occ_sampling_rate,
+                                              (0 if verify else 1) | (0 if keep_sa else 2))
+        else:
+            sa_arr = None if sa is None else np.ascontiguousarray(sa, "<u4")
+            self.h = lib().orc_index_create(*args, _ptr(sa_arr), sa_sampling_rate, occ_sampling_rate)
+        self.wide = wide
         if not self.h:
             raise RuntimeError("orc_index_create failed (invalid suffix array or text too long)")
 

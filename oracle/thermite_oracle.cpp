@@ -435,15 +435,18 @@ struct FMD {
   std::vector<usize> less;  // 257 entries: # symbols < c
   uint32_t occ_k = 128;
   int sym_of[256];
-  std::vector<uint32_t> occ;  // [n/k + 1][6]
+  // Every position and rank is a usize, as in the reference (src/index.rs:103-111: divsufsort64 -> Vec<usize>; a
+  // GRCh38-sized text has 6.2 G symbols).  The suffix array handed in may be 32- or 64-bit.
+  std::vector<usize> occ;  // [n/k + 1][6]
   // SampledSuffixArray
   uint32_t sa_s = 32;
-  std::vector<uint32_t> sa_sample;
-  std::unordered_map<usize, uint32_t> extra_rows;
-  // the plain suffix array is kept only for the matching-statistics cross-check
-  std::vector<uint32_t> sa_full;
+  std::vector<usize> sa_sample;
+  std::unordered_map<usize, usize> extra_rows;
+  // the plain suffix array is kept only for the matching-statistics cross-check (not for texts of billions of symbols)
+  std::vector<usize> sa_full;
 
-  void build(const uint8_t* text, usize n_, const uint32_t* sa, uint32_t sa_rate, uint32_t occ_rate) {
+  template <class SA>
+  void build(const uint8_t* text, usize n_, const SA* sa, uint32_t sa_rate, uint32_t occ_rate, bool keep_full = true) {
     n = n_;
     occ_k = occ_rate;
     sa_s = sa_rate;
@@ -461,7 +464,7 @@ struct FMD {
     // Occ::new: src/index.rs:110
     usize rows = n / occ_k + 1;
     occ.assign(rows * 6, 0);
-    uint32_t cur[6] = {0, 0, 0, 0, 0, 0};
+    usize cur[6] = {0, 0, 0, 0, 0, 0};
     for (usize i = 0; i < n; i++) {
       int s = sym_of[bwt[i]];
       if (s >= 0) cur[s]++;
@@ -472,11 +475,12 @@ struct FMD {
     sa_sample.clear();
     for (usize i = 0; i < n; i++) {
       if (i % sa_s == 0)
-        sa_sample.push_back(sa[i]);
+        sa_sample.push_back((usize)sa[i]);
       else if (bwt[i] == '$')
-        extra_rows[i] = sa[i];
+        extra_rows[i] = (usize)sa[i];
     }
-    sa_full.assign(sa, sa + n);
+    sa_full.clear();
+    if (keep_full) sa_full.assign(sa, sa + n);
   }
   inline usize less_of(uint8_t a) const { return less[a]; }
   // Occ::get: occurrences of a in bwt[0..=r]
@@ -647,7 +651,7 @@ struct orc_index {
   // MS[i] by binary search on the plain suffix array; SMEM iff end[i] > end[i-1];
   // emission order rebuilt from the all_smems i0 walk.
   std::vector<Mem> all_smems_ms(const uint8_t* q, usize L, usize k, usize* n_smems) const {
-    const std::vector<uint32_t>& sa = fmd.sa_full;
+    const std::vector<usize>& sa = fmd.sa_full;  // (kept by orc_index_create unless told otherwise)
     const usize n = text.size();
     struct S {
       usize pos, len, lo, hi;
@@ -1233,11 +1237,32 @@ int32_t orc_suffix_array_verify(const uint8_t* text, uint64_t n, const uint32_t*
   return 1;
 }
 
-orc_index* orc_index_create(const uint8_t* text, uint64_t n, const orc_ref* refs, uint32_t n_refs, const orc_tx* txs,
-                            uint32_t n_txs, const orc_exon* exons, uint64_t n_exons, const uint8_t* tx_seq,
-                            uint64_t n_tx_seq, const orc_span* genes, uint32_t n_genes, const uint32_t* name_rank,
-                            uint32_t n_names, const uint32_t* sa, uint32_t sa_rate, uint32_t occ_rate) {
-  if (n >= 0xFFFFFFFFull) return nullptr;
+int32_t orc_suffix_array_verify64(const uint8_t* text, uint64_t n, const uint64_t* sa) {
+  if (n == 0) return 1;
+  std::vector<uint64_t> rank(n + 1, 0);
+  std::vector<char> seen(n, 0);
+  for (uint64_t r = 0; r < n; r++) {
+    if (sa[r] >= n || seen[sa[r]]) return 0;
+    seen[sa[r]] = 1;
+    rank[sa[r]] = r + 1;  // rank[n] = 0: the empty suffix sorts first
+  }
+  for (uint64_t r = 0; r + 1 < n; r++) {
+    uint64_t a = sa[r], b = sa[r + 1];
+    if (text[a] > text[b]) return 0;
+    if (text[a] == text[b] && !(rank[a + 1] < rank[b + 1])) return 0;
+  }
+  return 1;
+}
+
+// sa32 or sa64 (exactly one): the suffix array of `text`.  flags bit 0: take it unverified (texts of billions of symbols: the
+// rank array of the check alone is 8 n bytes; the library's builder has its own check); bit 1: do not keep the plain suffix
+// array (the matching-statistics cross-check, orc_smems_ms, is not available then).
+static orc_index* index_create(const uint8_t* text, uint64_t n, const orc_ref* refs, uint32_t n_refs, const orc_tx* txs,
+                               uint32_t n_txs, const orc_exon* exons, uint64_t n_exons, const uint8_t* tx_seq,
+                               uint64_t n_tx_seq, const orc_span* genes, uint32_t n_genes, const uint32_t* name_rank,
+                               uint32_t n_names, const uint32_t* sa32, const uint64_t* sa64, uint32_t sa_rate, uint32_t occ_rate,
+                               uint32_t flags) {
+  if (!sa64 && n >= 0xFFFFFFFFull) return nullptr;
   orc_index* ix = new orc_index();
   ix->text.assign(text, text + n);
   for (uint32_t i = 0; i < n_refs; i++)
@@ -1245,15 +1270,19 @@ orc_index* orc_index_create(const uint8_t* text, uint64_t n, const orc_ref* refs
   ix->name_rank.assign(name_rank, name_rank + n_names);
   ix->tx_seq.assign(tx_seq, tx_seq + n_tx_seq);
   std::vector<uint32_t> own_sa;
-  if (!sa) {
+  if (!sa32 && !sa64) {
     own_sa.resize(n);
     orc_suffix_array_naive(text, n, own_sa.data());
-    sa = own_sa.data();
-  } else if (!orc_suffix_array_verify(text, n, sa)) {
+    sa32 = own_sa.data();
+  } else if (!(flags & 1u) && !(sa64 ? orc_suffix_array_verify64(text, n, sa64) : orc_suffix_array_verify(text, n, sa32))) {
     delete ix;
     return nullptr;
   }
-  ix->fmd.build(text, n, sa, sa_rate ? sa_rate : 32, occ_rate ? occ_rate : 128);
+  const bool keep_full = !(flags & 2u);
+  if (sa64)
+    ix->fmd.build(text, n, sa64, sa_rate ? sa_rate : 32, occ_rate ? occ_rate : 128, keep_full);
+  else
+    ix->fmd.build(text, n, sa32, sa_rate ? sa_rate : 32, occ_rate ? occ_rate : 128, keep_full);
   // transcripts + exon tree: src/index.rs:137-206.  Exons are inserted in the
   // order the `transcriptome` crate lists them (genomic order), i.e. before the
   // reverse() applied to '-' strand transcripts at :192-195.
@@ -1279,6 +1308,22 @@ orc_index* orc_index_create(const uint8_t* text, uint64_t n, const orc_ref* refs
   for (uint32_t g = 0; g < n_genes; g++) ix->gene_intervals.insert(genes[g].start, genes[g].end, g);
   ix->n_genes = n_genes;
   return ix;
+}
+orc_index* orc_index_create(const uint8_t* text, uint64_t n, const orc_ref* refs, uint32_t n_refs, const orc_tx* txs,
+                            uint32_t n_txs, const orc_exon* exons, uint64_t n_exons, const uint8_t* tx_seq,
+                            uint64_t n_tx_seq, const orc_span* genes, uint32_t n_genes, const uint32_t* name_rank,
+                            uint32_t n_names, const uint32_t* sa, uint32_t sa_rate, uint32_t occ_rate) {
+  return index_create(text, n, refs, n_refs, txs, n_txs, exons, n_exons, tx_seq, n_tx_seq, genes, n_genes, name_rank, n_names, sa, nullptr,
+                      sa_rate, occ_rate, 0);
+}
+// the same with a 64-bit suffix array: any text length, like the reference's Vec<usize> (src/index.rs:103-111, :364-388)
+orc_index* orc_index_create64(const uint8_t* text, uint64_t n, const orc_ref* refs, uint32_t n_refs, const orc_tx* txs,
+                              uint32_t n_txs, const orc_exon* exons, uint64_t n_exons, const uint8_t* tx_seq,
+                              uint64_t n_tx_seq, const orc_span* genes, uint32_t n_genes, const uint32_t* name_rank,
+                              uint32_t n_names, const uint64_t* sa, uint32_t sa_rate, uint32_t occ_rate, uint32_t flags) {
+  if (!sa) return nullptr;
+  return index_create(text, n, refs, n_refs, txs, n_txs, exons, n_exons, tx_seq, n_tx_seq, genes, n_genes, name_rank, n_names, nullptr, sa,
+                      sa_rate, occ_rate, flags);
 }
 void orc_index_free(orc_index* ix) { delete ix; }
 

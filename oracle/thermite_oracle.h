@@ -136,6 +136,14 @@ orc_index* orc_index_create(const uint8_t* text, uint64_t n, const orc_ref* refs
                             uint64_t n_tx_seq, const orc_span* genes, uint32_t n_genes, const uint32_t* name_rank,
                             uint32_t n_names, const uint32_t* sa, uint32_t sa_sampling_rate,
                             uint32_t occ_sampling_rate);
+/* The same with a 64-bit suffix array: any text length, like the reference's Vec<usize> (src/index.rs:103-111,
+ * :364-388).  flags bit 0: take the suffix array unverified (texts of billions of symbols); bit 1: do not keep the
+ * plain suffix array (the matching-statistics cross-check is not available then). */
+orc_index* orc_index_create64(const uint8_t* text, uint64_t n, const orc_ref* refs, uint32_t n_refs, const orc_tx* txs,
+                              uint32_t n_txs, const orc_exon* exons, uint64_t n_exons, const uint8_t* tx_seq,
+                              uint64_t n_tx_seq, const orc_span* genes, uint32_t n_genes, const uint32_t* name_rank,
+                              uint32_t n_names, const uint64_t* sa, uint32_t sa_rate, uint32_t occ_rate, uint32_t flags);
+int32_t orc_suffix_array_verify64(const uint8_t* text, uint64_t n, const uint64_t* sa);
 void orc_index_free(orc_index*);
 
 /* Index::all_smems (src/index.rs:228-255) through the FMD index */

@@ -335,6 +335,36 @@ def test_very_long_reads(chrm):
     check_align(chrm, b2, o2, dict(capi.CI_OPTS, min_aln_score_percent=0.5))
 
 
+def test_band_beyond_the_class_is_a_per_read_status(chrm):
+    """A read whose band does not fit the launch's class fails alone, with THM_ERR_INTERNAL (the reference asserts
+    band_width <= max_band_width per extend() call, src/swg.rs:32).  The classes are cut by read length and the band grows
+    with it, so only the debug hook can provoke the condition: the kernels pretend to hold bands up to +-40."""
+    rng = np.random.default_rng(5)
+    bases, off, _ = synth.simulate_reads(chrm.t, 3000, 91, sub_rate=0.02, indel_rate=0.002, stream=31)
+    reads = [bases[off[i]: off[i] + int(rng.integers(45, 92))] for i in range(3000)]
+    b2, o2 = refdata.pack_reads(reads)
+    lens = np.diff(o2.astype(np.int64))
+    r = chrm.oix.align_batch(b2, o2, capi.CI_OPTS, n_threads=8)  # CI flags: band = L - 30
+    for tpr in (False, True):
+        a = chrm.aligner(capi.CI_OPTS)
+        a.debug_set_flags(tpr=tpr)
+        a.debug_set_band_clip(40)
+        g = a.align_batch(b2, o2)
+        bad = lens - 30 > 40
+        assert bad.any() and (~bad).any()
+        assert g.n_failed == int(bad.sum()) and g.status is not None
+        assert (g.status[bad] == capi.ERR_INTERNAL).all() and (g.status[~bad] == 0).all()
+        n_g = np.diff(g.offsets.astype(np.int64))
+        n_r = np.diff(r.offsets.astype(np.int64))
+        assert (n_g[bad] == 0).all() and np.array_equal(n_g[~bad], n_r[~bad])
+        keep = np.repeat(~bad, n_r)
+        for f in ("score", "ystart", "yend", "xstart", "xend", "ref_id", "strand", "aln_type", "ops_len"):
+            assert np.array_equal(g.alns[f], r.alns[f][keep]), f
+        a.debug_set_band_clip(None)
+        assert_batch_equal(a.align_batch(b2, o2), r)
+        a.close()
+
+
 def test_reads_beyond_every_class_get_a_status(chrm):
     """a read longer than 65535 bases fails alone (per-read status), not the batch"""
     sb, so, _ = synth.simulate_reads(chrm.t, 200, 91, stream=101)

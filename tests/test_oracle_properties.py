@@ -58,3 +58,26 @@ def test_threshold_math_is_binary32(chrm):
     """(percent * L as f32) as i32, src/aligner.rs:131: 0.574f32 * 150f32 -> 86."""
     assert int(np.float32(0.574) * np.float32(150)) == 86
     assert int(np.float32(0.66) * np.float32(91)) == 60
+
+
+def test_usize_wide_index_equals_the_32_bit_one(syn):
+    """The oracle's FMD index with 64-bit positions and ranks throughout (the reference's own width, src/index.rs:103-111:
+    divsufsort64 -> Vec<usize>; the only width for texts of 2^32 symbols and more) gives what the 32-bit one gives."""
+    t, ix32 = syn
+    sa = capi.build_suffix_array(t["text"])
+    ix64 = orc.Index(t, sa=sa.astype("<u8"))
+    assert ix64.wide and not ix32.wide
+    bases, off, _ = synth.simulate_reads(t, 3000, 91, sub_rate=0.02, indel_rate=0.004, intronic_frac=0.3, stream=21)
+    for k in (12, 20):
+        a, b = ix32.all_smems(bases, off, k), ix64.all_smems(bases, off, k)
+        assert np.array_equal(a.offsets, b.offsets) and np.array_equal(a.mems, b.mems)
+        c = ix64.all_smems(bases, off, k, ms=True)
+        assert np.array_equal(a.mems, c.mems)
+    for opts in (capi.CI_OPTS, capi.DEFAULT_OPTS):
+        a, b = ix32.align_batch(bases, off, opts, n_threads=4), ix64.align_batch(bases, off, opts, n_threads=4)
+        assert np.array_equal(a.offsets, b.offsets) and np.array_equal(a.alns, b.alns) and np.array_equal(a.ops, b.ops)
+    # without verification and without the plain suffix array (how tools/big_text.py builds it on billions of symbols)
+    ix64b = orc.Index(t, sa=sa.astype("<u8"), verify=False, keep_sa=False)
+    b = ix64b.align_batch(bases, off, capi.CI_OPTS, n_threads=4)
+    a = ix32.align_batch(bases, off, capi.CI_OPTS, n_threads=4)
+    assert np.array_equal(a.alns, b.alns) and np.array_equal(a.ops, b.ops)

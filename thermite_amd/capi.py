@@ -233,6 +233,8 @@ def lib():
     if hasattr(L, "thm_debug_set_flags"):
         L.thm_debug_set_flags.restype = i32
         L.thm_debug_set_flags.argtypes = [vp, C.c_uint32]
+        L.thm_debug_set_band_clip.restype = i32
+        L.thm_debug_set_band_clip.argtypes = [vp, C.c_uint32]
         L.thm_debug_tpr_stats.restype = i32
         L.thm_debug_tpr_stats.argtypes = [vp, vp]
     if hasattr(L, "thm_debug_calib_gather"):
@@ -544,6 +546,10 @@ class Aligner:
         """test / tuning hook: tpr = False: every read takes the wave-per-read kernels, True: the problem-parallel path
         in front of them (None: keep); rounds = its request rounds (1..8, 0: keep)"""
         self._chk(lib().thm_debug_set_flags(self.h, (0 if tpr is None else (2 if tpr else 1)) | (int(rounds) << 8)))
+
+    def debug_set_band_clip(self, max_bw=None):
+        """test hook: the register-resident kernels pretend to hold bands up to max_bw only (None: off)"""
+        self._chk(lib().thm_debug_set_band_clip(self.h, 0 if max_bw is None else int(max_bw) + 1))
 
     def debug_tpr_stats(self):
         """the last run's problem-parallel path (thm_debug_tpr_stats)"""

@@ -423,6 +423,14 @@ int32_t thm_debug_set_flags(thm_aligner* a, uint32_t flags) {
   if (r >= 1 && r <= TPR_MAX_ROUNDS) a->tpr_rounds = r;
   return THM_OK;
 }
+// test hook: the register-resident kernels pretend their class holds bands up to `max_bw` only (max_bw + 1 is stored; 0 turns
+// the hook off): a read whose band is wider gets the per-read status THM_ERR_INTERNAL and no alignments -- the condition
+// the kernels guard against but cannot meet while the classes are cut by read length (src/swg.rs:32 asserts it per call)
+int32_t thm_debug_set_band_clip(thm_aligner* a, uint32_t max_bw_plus_1) {
+  if (!a) return THM_ERR_INVALID_ARG;
+  a->dbg_band_clip = max_bw_plus_1;
+  return THM_OK;
+}
 int32_t thm_debug_tpr_stats(thm_aligner* a, uint64_t stats[32]) {
   if (!a || !stats) return THM_ERR_INVALID_ARG;
   memset(stats, 0, 256);

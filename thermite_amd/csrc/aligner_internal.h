@@ -129,6 +129,7 @@ struct thm_aligner {
   uint64_t out_alns_cap = 0, out_ops_cap = 0;
   // test hook (thm_debug_set_pool_caps): initial pool sizes instead of the heuristics, to force the grow-and-replay path
   uint64_t dbg_smem_cap = 0, dbg_cand_cap = 0, dbg_ops_cap = 0;
+  uint32_t dbg_band_clip = 0;  // test hook (thm_debug_set_band_clip): pretend the fast class holds bands up to this only (0: off)
   uint32_t n_replays = 0;  // pool-overflow replays since the aligner was created
   bool ran = false, synced = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -30,8 +30,11 @@ namespace thm {
 namespace dev {
 
 // FAULT_OPS_POOL / FAULT_INTERNAL go to the batch's fault word; FAULT_CONTRACT (a condition that panics in the
-// reference) and FAULT_RETRY (more introns in one alignment than the fast kernel's marker list holds) are per read
-enum : int { FAULT_OPS_POOL = 1, FAULT_INTERNAL = 2, FAULT_CONTRACT = 4, FAULT_RETRY = 8 };
+// reference), FAULT_RETRY (more introns in one alignment than the fast kernel's marker list holds) and FAULT_BAND are per read
+// FAULT_BAND (per read): the read's band does not fit this launch's class (cannot happen while the band is monotone in the
+// read length, which is how the classes are cut; the reference's own check, assert!(band_width <= max_band_width) at
+// src/swg.rs:32, is per call): the read gets the status THM_ERR_INTERNAL and no alignments, the batch goes on
+enum : int { FAULT_OPS_POOL = 1, FAULT_INTERNAL = 2, FAULT_CONTRACT = 4, FAULT_RETRY = 8, FAULT_BAND = 16 };
 
 // signed type that holds a text coordinate of width C and small negative offsets from it
 template <class C>
@@ -835,8 +838,10 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
     int x_drop = band_width;
     const int range = (int)p.opts.multimap_score_range;
     const bool intron_mode = p.opts.intron_mode != 0;
+    bool band_bad = false;
     if (band_width > (int)p.max_bw || (CPL > 0 && 2 * band_width + 1 > 64 * CPL)) {
-      c.fault |= FAULT_INTERNAL;
+      c.fault |= FAULT_BAND;
+      band_bad = true;
       band_width = x_drop = 0;
     }
 
@@ -866,6 +871,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
       c.fault |= FAULT_OPS_POOL;
       n_sm = 0;
     }
+    if (band_bad) n_sm = 0;  // no hit is extended
 #ifdef THM_PROF
     c.prof_hit = 0;
 #endif
@@ -1358,7 +1364,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
         t_res[wave][2] = band_width;
         t_res[wave][3] = x_drop;
         t_res[wave][4] = max_aln_score;
-        t_res[wave][5] = active ? (c.fault & (FAULT_RETRY | FAULT_CONTRACT)) : 0;
+        t_res[wave][5] = active ? (c.fault & (FAULT_RETRY | FAULT_CONTRACT)) : 0;  // (FAULT_BAND is set before the rounds, by every wave alike)
       }
       __syncthreads();
       int valid = (int)min((unsigned)TEAM, t_total > t_base ? t_total - t_base : 0u);
@@ -1419,6 +1425,14 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
       }
       c.cells = c.cols = c.calls = c.winbytes = 0;
       continue;
+    }
+    if (c.fault & FAULT_BAND) {
+      c.fault &= ~FAULT_BAND;
+      n_acc = 0;
+      if (lead && lane == 0) {
+        p.read_status[idx] = THM_ERR_INTERNAL;
+        atomicAdd(p.n_contract, 1ull);  // (tells the host to fetch the statuses)
+      }
     }
     if (c.fault & FAULT_CONTRACT) {
       // a condition that panics in the reference (lift_mem_to_tx / lift_tx_to_gx): no alignments, per-read status

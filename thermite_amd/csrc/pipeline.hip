@@ -243,6 +243,7 @@ int enqueue_extend_t(thm_aligner* a, const ExtClasses& cls, uint32_t mk_cap_slow
   // ---- fast class ----
   ep.max_read_len = cls.fast_len;
   ep.max_bw = cls.fast_bw;
+  if (a->dbg_band_clip) ep.max_bw = std::min<uint32_t>(ep.max_bw, a->dbg_band_clip - 1);  // test hook: reads beyond get THM_ERR_INTERNAL
   ep.mk_cap = FAST_MAX_YCLIPS;
   ep.list_only = 0;
   const int cpl = std::max(1, (int)((2 * cls.fast_bw + 1 + 63) / 64));
