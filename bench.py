@@ -88,7 +88,9 @@ def csrc_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "thermite_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
+        # the device code and what it is built with (the host-side file I/O, index construction and suffix sorting do not
+        # change what a kernel does)
+        if (f.endswith((".hip", ".h")) and not f.startswith("io_")) or f == "Makefile":
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -141,6 +143,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the extra figures (value_e2e, value_two_in_flight): profiling passes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dump-digest", default=None,
+                    help="write PATH.<rank>.json: SHA-256 of this rank's alignment records and op streams per batch (tests compare them "
+                         "with the CPU oracle's for the same shard)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,6 +196,7 @@ def main():
         tag = "%d_%x" % (ref_len, synth.SEED)
     sa = load_suffix_array(capi, tables, rank, world, dist, tag)
     index = capi.Index(tables, sa=sa, wide=args.wide)
+    t_index = time.time() - t0
     log(rank, "reference: %s %d bp, text n=%d, %d transcripts, %d exons; index (%d-byte coordinates) in %.1fs" % (
         args.workload, ref_len, len(tables["text"]), len(tables["txs"]), len(tables["exons"]), index.coord_bytes, time.time() - t0))
     opts = dict(capi.CI_OPTS if args.opts == "ci" else capi.DEFAULT_OPTS)
@@ -214,6 +220,7 @@ def main():
         reads_this_rank = per
         desc_reads = "%d synthetic %d bp reads per GPU per step, %d distinct resident batches in rotation" % (per, L, nb)
     NB = len(batches)
+    t_reads = time.time() - t0
     log(rank, "reads: %s; rank 0 holds %d x %d reads (generated in %.1fs)" % (desc_reads, NB, reads_this_rank, time.time() - t0))
     aligners = [capi.Aligner(index, opts, device=local_rank) for _ in range(NB)]
     for a, (bases, offsets) in zip(aligners, batches):
@@ -225,6 +232,29 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # per-rank set-up times (index build / load, read generation): rank 0 reports them all (a slow rank shows before the run)
+    setup = torch.tensor([t_index, t_reads], dtype=torch.float64, device=cdev)
+    setup_all = [setup]
+    if world > 1:
+        setup_all = [torch.zeros_like(setup) for _ in range(world)]
+        dist.all_gather(setup_all, setup)
+    per_rank_setup = [{"rank": r, "index_s": round(float(v[0]), 2), "reads_s": round(float(v[1]), 2)} for r, v in enumerate(setup_all)]
+    log(rank, "set-up seconds per rank (index, reads): " + ", ".join("%d: %.1f / %.1f" % (d["rank"], d["index_s"], d["reads_s"]) for d in per_rank_setup))
+    if args.dump_digest:
+        import hashlib
+
+        digs = []
+        for a in aligners:
+            g = a.fetch()
+            h = hashlib.sha256()
+            h.update(np.ascontiguousarray(g.offsets).tobytes())
+            for f in capi.ALN_DT.names:
+                if f != "pad_":
+                    h.update(np.ascontiguousarray(g.alns[f]).tobytes())
+            h.update(np.ascontiguousarray(g.ops).tobytes())
+            digs.append({"reads": int(g.n_reads), "alignments": int(len(g.alns)), "sha256": h.hexdigest()})
+        json.dump({"rank": rank, "world": world, "batches": digs}, open("%s.%d.json" % (args.dump_digest, rank), "w"))
 
     # ---------------- warmup ----------------
     for i in range(args.warmup):
@@ -416,6 +446,7 @@ def main():
                 "coord_bytes": index.coord_bytes, "batches_in_flight": max(1, min(args.inflight, NB)),
                 "parallelism": "reads sharded over %d GPU(s), index replicated, 1 counter all-reduce" % world,
             },
+            "per_rank_setup_s": per_rank_setup,
             "roofline": roofline,
             "roofline_valu": roofline_valu,
             "value_is": "batches resident in HBM before the timed region (the task's contract); value_e2e is the rate with host<->device "

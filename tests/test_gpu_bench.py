@@ -43,11 +43,14 @@ def test_bench_line_single_gpu():
     assert abs(d["value"] - 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
 
 
-def test_bench_two_ranks_sharded_stream():
+def test_bench_two_ranks_sharded_stream(tmp_path):
+    """the N > 1 path end to end: both ranks' ALIGNMENTS (not only the read counter) against the CPU oracle on the same
+    shards of the one seeded stream"""
     port = _free_port()
+    dig = str(tmp_path / "digest")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "bench.py", "--gpus", "2", "--backend", "gloo", "--one-device", "--total-reads", "300000",
-           "--ref-len", "4000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+           "--ref-len", "4000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dump-digest", dig]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run(cmd, cwd=ROOT, check=True, capture_output=True, timeout=900, env=env).stdout
     d = _last_json(out)
@@ -55,3 +58,29 @@ def test_bench_two_ranks_sharded_stream():
     assert d["config"]["reads_per_gpu_per_step"] == 150000
     assert d["counters"]["reads"] == 2 * 300000  # both ranks' shards, both steps, summed by the all-reduce
     assert abs(d["value"] - 300000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert [x["rank"] for x in d["per_rank_setup_s"]] == [0, 1]
+    # the oracle on each rank's shard
+    import hashlib
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import pyoracle as orc
+    from thermite_amd import capi, sharding, synth
+
+    tables = synth.synth_reference(length=4000000)
+    oix = orc.Index(tables, sa=capi.build_suffix_array(tables["text"]))
+    for rank in (0, 1):
+        got = json.load(open("%s.%d.json" % (dig, rank)))
+        b, e = sharding.shard_bounds(300000, rank, 2)
+        bases, off = bench.stream_reads(synth, tables, b, e, 91)
+        r = oix.align_batch(bases, off, capi.CI_OPTS, n_threads=16)
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(r.offsets).tobytes())
+        for f in capi.ALN_DT.names:
+            if f != "pad_":
+                h.update(np.ascontiguousarray(r.alns[f]).tobytes())
+        h.update(np.ascontiguousarray(r.ops).tobytes())
+        assert got["batches"][0]["reads"] == e - b and got["batches"][0]["alignments"] == len(r.alns)
+        assert got["batches"][0]["sha256"] == h.hexdigest(), "rank %d: alignments differ from the oracle" % rank

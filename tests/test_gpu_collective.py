@@ -28,6 +28,26 @@ def test_single_rank_rccl_allreduce_is_identity(data_dir):
     a.close()
 
 
+def test_allreduce_argument_checks(data_dir):
+    """null handles are THM_ERR_INVALID_ARG, never a crash; a communicator that was freed is not touched again"""
+    import ctypes as C
+
+    L = capi.lib()
+    t = refdata.load_reference(data_dir + "/test_ref.fasta", data_dir + "/test_ref.gtf")
+    a = capi.Aligner(capi.Index(t), capi.CI_OPTS)
+    comm = capi.Comm(capi.comm_unique_id(), 1, 0, 0)
+    assert L.thm_counters_allreduce(None, comm.h) == capi.ERR_INVALID_ARG
+    assert L.thm_counters_allreduce(a.h, None) == capi.ERR_INVALID_ARG
+    assert L.thm_comm_unique_id(None) == capi.ERR_INVALID_ARG
+    out = C.c_void_p()
+    assert L.thm_comm_create(None, 1, 0, 0, C.byref(out)) == capi.ERR_INVALID_ARG and not out.value
+    assert L.thm_comm_create(capi._ptr(capi.comm_unique_id()), 1, 0, 0, None) == capi.ERR_INVALID_ARG
+    L.thm_comm_free(None)  # a no-op
+    a.counters_allreduce(comm)  # still usable after the failed calls
+    comm.close()
+    a.close()
+
+
 def test_comm_argument_checks():
     uid = np.zeros(128, np.uint8)
     for nranks, rank in ((0, 0), (2, 2), (1, -1)):

@@ -294,10 +294,11 @@ __device__ __forceinline__ int swg_and_trace(W& c, const uint8_t* xs, int dx, in
     PROF_MARK(c, PS_DP);
     n = swg_traceback_wave<1>(c.trace, r.xend, r.yend, bw, ops, stride, max_ops);
   } else if (CPL > 2 && min(2 * bw + 1, xlen + 1) <= 128) {
-    // fits two cells per lane: a third fewer instructions per column than the kernel's own width
-    unsigned long long* tr = c.trace_g;
+    // fits two cells per lane: a third fewer instructions per column than the kernel's own width, and the trace stays in
+    // LDS (ext_caps: these kernels' LDS trace holds two cells per lane)
+    unsigned long long* tr = c.trace;
     r = swg_extend_wave<2>(xs, dx, xlen, ys, dy, ylen, bw, xd, tr);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    wsync(c);
     PROF_MARK(c, PS_DP);
     n = swg_traceback_wave<2>(tr, r.xend, r.yend, bw, ops, stride, max_ops);
   } else {
@@ -584,12 +585,17 @@ constexpr int TEAM_CHUNK = 4;           // hits per chunk of a team
 struct ExtCaps {
   uint32_t lcap, wcap, ycols, trb, opcap;
 };
-__host__ __device__ inline ExtCaps ext_caps(uint32_t max_read_len, uint32_t max_bw) {
+// cpl: cells per lane of the kernel's widest band (0: the any-width kernel)
+__host__ __device__ inline ExtCaps ext_caps(uint32_t max_read_len, uint32_t max_bw, int cpl = 1) {
   ExtCaps k;
   k.lcap = (max_read_len + 31u) & ~15u;
   k.wcap = (2u * (max_read_len + max_bw) + max_read_len + 48u) & ~15u;
   k.ycols = max_read_len + max_bw + 2u;
-  k.trb = (k.ycols + 1u) * 16u;  // LDS trace: one cell per lane; wider extensions use trace_g
+  // LDS trace: one cell per lane (16 bytes per column).  The kernels for bands beyond 128 slots (three and four cells per
+  // lane: 150 bp reads with a band of +-64) keep room for two cells per lane: most of their extensions have 65..128 slots
+  // (min(2 bw + 1, |x| + 1)), and a trace in global memory -- a store per column, an agent-scope fence, a traceback of
+  // dependent global loads -- is what such a launch was spending its time on.  Wider extensions still use trace_g.
+  k.trb = (k.ycols + 1u) * (cpl >= 3 ? 32u : 16u);
   k.opcap = (2u * max_read_len + 2u * max_bw + 31u) & ~15u;
   return k;
 }
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(TEAM > 0 ? 64 * TEAM : 256, TEAM > 0 ? 1 : MINW) vo
   const int wave = bcast_first((int)(threadIdx.x >> 6));  // wave-uniform: LDS bases stay on the scalar unit
   const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
   // ---- wave-private buffers (LDS carve must match extend_lds_bytes; global layout = slow_layout) ----
-  const ExtCaps caps = ext_caps(p.max_read_len, p.max_bw);
+  const ExtCaps caps = ext_caps(p.max_read_len, p.max_bw, CPL);
   const uint32_t lcap = caps.lcap, wcap = caps.wcap, opcap = caps.opcap;
   Wctx c;
   if constexpr (GS) {
@@ -1872,9 +1878,8 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
 }  // namespace dev
 
 size_t extend_lds_bytes(uint32_t max_read_len, uint32_t max_bw, int cpl) {
-  const dev::ExtCaps k = dev::ext_caps(max_read_len, max_bw);
+  const dev::ExtCaps k = dev::ext_caps(max_read_len, max_bw, cpl);
   const uint32_t per_wave = k.lcap + 2u * k.wcap + k.trb + 3u * k.opcap + 8u * FAST_MAX_YCLIPS + (uint32_t)(dev::KEYCAP * sizeof(dev::CandKey));
-  (void)cpl;
   return 4 * (size_t)per_wave;
 }
 
@@ -1888,6 +1893,7 @@ size_t extend_slow_scratch_bytes(uint32_t max_read_len, uint32_t max_bw, uint32_
   return (size_t)dev::slow_layout(max_read_len, max_bw, mk_cap).total;
 }
 
+constexpr int EXT_MINW_CPL34 = 4;  // default register budget of the three- and four-cell kernels (waves per SIMD)
 // waves per SIMD the wave-per-read kernel chosen for (cpl, coordinate width) is compiled for = workgroups of 4 waves
 // that fit a CU; the host launches no more than that (a workgroup beyond it starts when the first ones leave, finds
 // the work counters dry and only delays the end of the launch)
@@ -1898,7 +1904,15 @@ int extend_waves_per_simd(int cpl, bool wide) {
     return (v >= 4 && v <= 8) ? v : 0;
   }();
   if (cpl == 0) return 2;
-  if (cpl > 2) return 4;
+  if (cpl > 2) {
+    // three and four cells per lane (bands beyond +-63: BASELINE config 5's +-64): tuning knob THM_EXT_MINW_CPL3 = 3 | 4 | 5 | 6
+    static const int v34 = [] {
+      const char* e = getenv("THM_EXT_MINW_CPL3");
+      const int v = e ? atoi(e) : 0;
+      return (v >= 3 && v <= 6) ? v : 0;
+    }();
+    return (v34 && !wide) ? v34 : EXT_MINW_CPL34;
+  }
   if (wide) {
     static const int wide_env = [] {
       const char* e = getenv("THM_EXT_MINW_WIDE");
@@ -1963,8 +1977,20 @@ static hipError_t launch_extend_t(const ExtendParamsT<C>& p, int cpl, int n_bloc
         if (minw == 5) return go(dev::extend_kernel<C, 2, 5>);
         if (minw == 8) return go(dev::extend_kernel<C, 2, 8>);
         return go(dev::extend_kernel<C, 2, 6>);
-      case 3: return go(dev::extend_kernel<C, 3, 4>);
-      case 4: return go(dev::extend_kernel<C, 4, 4>);
+      case 3:
+      case 4: {
+        const int minw = extend_waves_per_simd(cpl, false);
+        if (cpl == 3) {
+          if (minw == 3) return go(dev::extend_kernel<C, 3, 3>);
+          if (minw == 5) return go(dev::extend_kernel<C, 3, 5>);
+          if (minw == 6) return go(dev::extend_kernel<C, 3, 6>);
+          return go(dev::extend_kernel<C, 3, 4>);
+        }
+        if (minw == 3) return go(dev::extend_kernel<C, 4, 3>);
+        if (minw == 5) return go(dev::extend_kernel<C, 4, 5>);
+        if (minw == 6) return go(dev::extend_kernel<C, 4, 6>);
+        return go(dev::extend_kernel<C, 4, 4>);
+      }
       default: return hipErrorInvalidValue;
     }
   }
