@@ -366,3 +366,96 @@ def test_index_load_rejects_absurd_header_counts(data_dir, tmp_path):
             with pytest.raises(capi.ThermiteError) as e:
                 capi.Index.load(q)
             assert e.value.code == capi.ERR_FORMAT
+
+
+# ---- the library's own inflate (csrc/io_inflate.cpp) against Python's gzip / zlib ----
+def _gz_cases():
+    rng = np.random.default_rng(11)
+    fastq = b"".join(b"@r%d x\n" % i + bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 91)]) + b"\n+\n" + b"F" * 91 + b"\n" for i in range(20000))
+    noise = rng.integers(0, 256, 300000, dtype=np.uint8).tobytes()
+    skew = bytes(rng.choice(np.arange(256, dtype=np.uint8), 400000, p=np.r_[np.full(4, 0.2), np.full(252, 0.2 / 252)]))  # long and short codes
+    runs = b"".join(bytes([int(c)]) * int(n) for c, n in zip(rng.integers(65, 70, 3000), rng.integers(1, 700, 3000)))  # distances 1..8, lengths to 258
+    periodic = b"".join((b"abcdefghijklmnopqrstuvwxyz"[: int(k)]) * 40 for k in rng.integers(1, 26, 400))  # every short distance
+    return {"fastq": fastq, "noise": noise, "skew": skew, "runs": runs, "periodic": periodic, "empty": b"", "one": b"A", "short": b"hello hello hello hello\n"}
+
+
+@pytest.mark.parametrize("chunk", [1024, 4096, 1 << 20])
+def test_inflate_equals_zlib(tmp_path, chunk):
+    import zlib
+    for name, data in _gz_cases().items():
+        for level in (0, 1, 6, 9):
+            p = tmp_path / ("%s_%d.gz" % (name, level))
+            p.write_bytes(gzip.compress(data, level))
+            assert capi.debug_gunzip(p, chunk) == data, (name, level, chunk)
+        # fixed-Huffman blocks, and a stream cut into many blocks by full flushes
+        for strategy, tag in ((zlib.Z_FIXED, "fixed"), (zlib.Z_DEFAULT_STRATEGY, "flushed")):
+            co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, strategy)
+            z = b""
+            for s in range(0, len(data), 7001):
+                z += co.compress(data[s : s + 7001])
+                if tag == "flushed":
+                    z += co.flush(zlib.Z_FULL_FLUSH if (s // 7001) % 2 else zlib.Z_SYNC_FLUSH)
+            z += co.flush()
+            p = tmp_path / ("%s_%s.gz" % (name, tag))
+            p.write_bytes(z)
+            assert capi.debug_gunzip(p, chunk) == data, (name, tag, chunk)
+
+
+def test_inflate_members_and_headers(tmp_path):
+    import io, struct, zlib
+    cases = _gz_cases()
+    # several members back to back (bgzip, `cat a.gz b.gz`): the stream is their concatenation
+    p = tmp_path / "members.gz"
+    p.write_bytes(b"".join(gzip.compress(cases[k], lv) for k, lv in (("fastq", 1), ("empty", 6), ("noise", 6), ("short", 9), ("fastq", 6))))
+    want = cases["fastq"] + cases["noise"] + cases["short"] + cases["fastq"]
+    for chunk in (1024, 1 << 20):
+        assert capi.debug_gunzip(p, chunk) == want
+    # every optional header field: FEXTRA, FNAME, FCOMMENT, FHCRC
+    body = zlib.compress(cases["fastq"], 6)[2:-4]
+    hdr = bytes([0x1F, 0x8B, 8, 4 | 8 | 16, 0, 0, 0, 0, 0, 3]) + struct.pack("<H", 6) + b"BC\x02\x00\x12\x34" + b"name.fastq\0" + b"a comment\0"
+    hdr_crc = bytes([0x1F, 0x8B, 8, 2 | 4 | 8 | 16]) + hdr[4:]
+    hdr_crc += struct.pack("<H", zlib.crc32(hdr_crc) & 0xFFFF)
+    tail = struct.pack("<II", zlib.crc32(cases["fastq"]), len(cases["fastq"]) & 0xFFFFFFFF)
+    for k, h in enumerate((hdr, hdr_crc)):
+        p = tmp_path / ("hdr%d.gz" % k)
+        p.write_bytes(h + body + tail)
+        assert gzip.decompress(p.read_bytes()) == cases["fastq"]
+        assert capi.debug_gunzip(p) == cases["fastq"]
+    # bytes behind the last member that are no member are ignored, as gzread does (zero padding of a tape block)
+    p = tmp_path / "padded.gz"
+    p.write_bytes(gzip.compress(cases["short"]) + b"\0" * 512)
+    assert capi.debug_gunzip(p) == cases["short"]
+
+
+def test_inflate_bad_streams_are_errors(tmp_path):
+    import struct
+    data = _gz_cases()["fastq"]
+    z = gzip.compress(data, 6)
+    bad = {}
+    for cut in (5, 10, 11, 40, len(z) // 3, len(z) - 9, len(z) - 8, len(z) - 1):
+        bad["cut%d" % cut] = z[:cut]
+    bad["crc"] = z[:-8] + struct.pack("<I", (struct.unpack("<I", z[-8:-4])[0] ^ 1)) + z[-4:]
+    bad["isize"] = z[:-4] + struct.pack("<I", len(data) + 1)
+    bad["method"] = z[:2] + b"\x07" + z[3:]
+    bad["reserved_flags"] = z[:3] + b"\x20" + z[4:]
+    bad["second_member_cut"] = z + z[: len(z) // 2]
+    bad["not_gzip"] = b"@r0\nACGT\n+\nFFFF\n"
+    rng = np.random.default_rng(3)
+    for k in range(40):  # bit flips anywhere in the deflate stream: caught by the stream's structure or by the CRC
+        zb = bytearray(z)
+        at = int(rng.integers(10, len(z) - 8))
+        zb[at] ^= 1 << int(rng.integers(0, 8))
+        bad["flip%d" % k] = bytes(zb)
+    for name, b in bad.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(b)
+        with pytest.raises(capi.ThermiteError) as e:
+            capi.debug_gunzip(p, 4096)
+        assert e.value.code == capi.ERR_IO, name
+    # a stored block's LEN / NLEN pair
+    zs = bytearray(gzip.compress(data[:1000], 0))
+    zs[13] ^= 0xFF
+    p = tmp_path / "stored.gz"
+    p.write_bytes(bytes(zs))
+    with pytest.raises(capi.ThermiteError):
+        capi.debug_gunzip(p)

@@ -208,6 +208,9 @@ def lib():
     L.thm_fastq_next_batch.restype = i32
     L.thm_fastq_next_batch.argtypes = [vp, u64, vp]
     L.thm_fastq_close.argtypes = [vp]
+    if hasattr(L, "thm_debug_gunzip"):
+        L.thm_debug_gunzip.restype = i32
+        L.thm_debug_gunzip.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
     if hasattr(L, "thm_debug_fastq_blocks"):
         L.thm_debug_fastq_blocks.restype = i32
         L.thm_debug_fastq_blocks.argtypes = [vp, u64, vp]
@@ -604,6 +607,17 @@ class Comm:
 
     def __del__(self):
         self.close()
+
+
+def debug_gunzip(path, chunk=1 << 20, cap=None):
+    """test hook: a gzip file through the library's own inflater, `chunk` bytes per call -> bytes"""
+    cap = cap if cap is not None else 64 * os.path.getsize(path) + (1 << 20)
+    out = np.empty(cap, np.uint8)
+    n = C.c_uint64(0)
+    rc = lib().thm_debug_gunzip(os.fsencode(str(path)), chunk, out.ctypes.data, cap, C.byref(n))
+    if rc != 0:
+        raise ThermiteError(rc, _last_error())
+    return out[: n.value].tobytes()
 
 
 class FastqReader:

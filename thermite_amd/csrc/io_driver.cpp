@@ -1,7 +1,9 @@
 // io_driver.cpp -- whole-file driver (include/thermite_io.h): the loop of
 // align_reads_from_file, reference src/aligner.rs:22-120, as overlapped stages over
 // batches of reads:
-//     cut     one thread: file bytes (read(2) / zlib) -> blocks of whole FASTQ records
+//     inflate one thread per gzip input file, a few files at a time: gzip bytes -> blocks of whole FASTQ
+//             records, ahead of the file's turn within a memory budget (the records still leave in input order)
+//     cut     one thread: mapped file bytes / the inflaters' blocks -> slots, in input order
 //     parse   a few threads: block -> batch (names, bases, qualities)
 //     GPU     one thread per aligner (= per GPU): upload, run, sync, fetch
 //     write   one thread: batches in input order -> formatting threads -> pwrite
@@ -18,9 +20,11 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -46,6 +50,111 @@ struct Slot {
   thm::HostBatch reads;
   thm_batch_view res;  // into the pinned result buffers of the aligner that ran it (two sets per aligner, used alternately)
   bool aligned = false;
+};
+
+// A gzip FASTQ file on a thread of its own: inflate, cut into blocks of whole records, queue.  The reference reads its
+// query files one after the other (src/aligner.rs:51); so does the cutter -- but an inflater decodes only about a
+// gigabyte a second, several times less than the stages behind it take, so the inflaters of the next files start
+// early and run ahead of their turn until their share of the budget is queued.  (Nothing of this reorders the
+// output: the cutter takes the files' blocks strictly in input order.)
+struct Ahead {
+  struct Block {
+    std::vector<char> raw;
+    size_t raw_len = 0;
+    uint64_t n_lines = 0, first_line = 0;
+    bool last_block = false;
+    int rc = THM_OK;
+    std::string err;
+  };
+  std::string path;
+  uint64_t batch_reads = 0;
+  size_t budget = 0;  // bytes this file may hold queued (one more block is cut once the queue is below it)
+  thm_fastq* r = nullptr;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Block> ready;
+  std::vector<std::vector<char>> spare;
+  size_t queued = 0;
+  int kind = -1;  // -1 not known yet; 0 not 4-line FASTQ (the cutter runs the sequential parser on `r`); 1 blocks; 2 cannot open
+  int open_rc = THM_OK;
+  std::string open_err;
+  bool cancel = false;
+  double busy_s = 0;
+
+  void run() {
+    const auto t0 = Clock::now();
+    int rc = thm_fastq_open(path.c_str(), &r);
+    bool fast = false;
+    if (rc == THM_OK) fast = thm::fastq_is_plain_fastq(r);
+    busy_s += secs(t0, Clock::now());
+    {
+      std::lock_guard<std::mutex> g(mu);
+      open_rc = rc;
+      if (rc != THM_OK) open_err = thm_last_error(nullptr);
+      kind = rc != THM_OK ? 2 : (fast ? 1 : 0);
+    }
+    cv.notify_all();
+    if (!fast) return;
+    for (;;) {
+      Block b;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return queued < budget || cancel; });
+        if (cancel) return;
+        if (!spare.empty()) {
+          b.raw.swap(spare.back());
+          spare.pop_back();
+        }
+      }
+      const auto t1 = Clock::now();
+      try {
+        b.rc = thm::fastq_next_raw_block(r, batch_reads, b.raw, b.raw_len, b.n_lines, b.first_line, b.last_block);
+        if (b.rc != THM_OK) b.err = thm_last_error(nullptr);
+      } catch (const std::bad_alloc&) {
+        b.rc = THM_ERR_OOM;
+        b.err = "out of host memory inflating " + path;
+      }
+      busy_s += secs(t1, Clock::now());
+      const bool last = b.rc != THM_OK || b.n_lines == 0;
+      {
+        std::lock_guard<std::mutex> g(mu);
+        queued += b.raw_len;
+        ready.push_back(std::move(b));
+      }
+      cv.notify_all();
+      if (last) return;
+    }
+  }
+  void start() {
+    th = std::thread([this] { run(); });
+  }
+  int wait_kind() {
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return kind >= 0; });
+    return kind;
+  }
+  // the next block of the file (the last one holds no line, or an error); `old` goes back for reuse
+  void next(Block& out, std::vector<char>& old) {
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return !ready.empty(); });
+    out = std::move(ready.front());
+    ready.pop_front();
+    queued -= out.raw_len;
+    if (old.capacity()) spare.emplace_back(std::move(old));
+    g.unlock();
+    cv.notify_all();
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      cancel = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+    if (r) thm_fastq_close(r);
+    r = nullptr;
+  }
 };
 
 // blocking queue of slot pointers; nullptr = end of stream
@@ -182,14 +291,58 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
   // ---- stage 1: cut the input into blocks of whole records ----
   std::thread cutter([&] {
     uint64_t seq = 0;
+    // gzip inputs get an inflater thread each (Ahead), those of the next few files running ahead of their turn
+    std::vector<std::unique_ptr<Ahead>> ahead(n_paths);
+    std::vector<char> is_gz(n_paths, 0);
+    unsigned n_gz = 0;
+    for (uint32_t pi = 0; pi < n_paths; pi++) {
+      unsigned char magic[2] = {0, 0};
+      const int fd = open(fastq_paths[pi], O_RDONLY);
+      if (fd >= 0) {
+        is_gz[pi] = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        close(fd);
+      }
+      n_gz += is_gz[pi];
+    }
+    const unsigned ahead_files = std::max(1u, std::min(n_gz, std::max(2u, n_threads / 4)));
+    size_t ahead_bytes = (size_t)2048 << 20;  // all inflaters together; THM_INFLATE_AHEAD_MB overrides
+    if (const char* e = getenv("THM_INFLATE_AHEAD_MB")) ahead_bytes = (size_t)std::max(1L, atol(e)) << 20;
+    auto top_up = [&](uint32_t from) {  // the inflaters of the next `ahead_files` gzip files at or behind `from`
+      unsigned running = 0;
+      for (uint32_t k = from; k < n_paths && running < ahead_files; k++) {
+        if (!is_gz[k]) continue;
+        running++;
+        if (ahead[k]) continue;
+        ahead[k].reset(new Ahead());
+        ahead[k]->path = fastq_paths[k];
+        ahead[k]->batch_reads = batch_reads;
+        ahead[k]->budget = ahead_bytes / ahead_files;
+        ahead[k]->start();
+      }
+    };
     for (uint32_t pi = 0; pi < n_paths && !sh.failed(); pi++) {
       thm_fastq* r = nullptr;
-      int prc = thm_fastq_open(fastq_paths[pi], &r);
-      if (prc != THM_OK) {
-        sh.set(prc, thm_last_error(nullptr));
-        break;
+      Ahead* ah = nullptr;
+      int prc = THM_OK;
+      bool fast = false;
+      if (sh.step([&] { top_up(pi); return THM_OK; }) != THM_OK) break;
+      if (is_gz[pi]) {
+        ah = ahead[pi].get();
+        const int kind = ah->wait_kind();
+        if (kind == 2) {
+          sh.set(ah->open_rc, ah->open_err);
+          break;
+        }
+        fast = kind == 1;
+        r = ah->r;  // (the sequential parser's, when the file is not 4-line FASTQ: the inflater thread has left)
+      } else {
+        prc = thm_fastq_open(fastq_paths[pi], &r);
+        if (prc != THM_OK) {
+          sh.set(prc, thm_last_error(nullptr));
+          break;
+        }
+        fast = thm::fastq_is_plain_fastq(r);
       }
-      const bool fast = thm::fastq_is_plain_fastq(r);
       // a plain (not gzip) FASTQ file is mapped and cut in place: a block is a range of the mapping
       const char* map = nullptr;
       size_t map_len = 0, map_pos = 0;
@@ -250,6 +403,17 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
           map_line += n_lines;
           map_pos = p;
           prc = THM_OK;
+        } else if (fast && ah) {
+          Ahead::Block b;
+          ah->next(b, s->raw);
+          s->raw.swap(b.raw);
+          s->raw_len = b.raw_len;
+          s->first_line = b.first_line;
+          s->last_block = b.last_block;
+          n_lines = b.n_lines;
+          prc = b.rc;
+          if (prc != THM_OK) thm::set_global_error(b.err);
+          s->raw_ptr = s->raw.data();
         } else if (fast) {
           prc = sh.step([&] { return thm::fastq_next_raw_block(r, batch_reads, s->raw, s->raw_len, n_lines, s->first_line, s->last_block); });
           s->raw_ptr = s->raw.data();
@@ -258,7 +422,7 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
           s->parsed = true;
           n_lines = s->reads.n_reads();
         }
-        {
+        if (!(fast && ah)) {  // (an inflater thread counts its own time)
           std::lock_guard<std::mutex> g(st_mu);
           st.parse_s += secs(t0, Clock::now());
         }
@@ -270,9 +434,17 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
         seq++;
         q_raw.push(s);
       }
-      thm_fastq_close(r);
+      if (ah) {
+        ah->stop();  // (closes the reader)
+        std::lock_guard<std::mutex> g(st_mu);
+        st.parse_s += ah->busy_s;
+      } else {
+        thm_fastq_close(r);
+      }
       if (map) maps.emplace_back(map, map_len);  // unmapped when every batch has been written
     }
+    for (auto& a : ahead)
+      if (a) a->stop();  // (inflaters started ahead of a run that failed)
     {
       std::lock_guard<std::mutex> g(done_mu);
       n_batches_cut = seq;

@@ -3,10 +3,9 @@
 // of align_reads_from_file (reference src/aligner.rs:51-56): record.id() is the
 // whole header line without its '@' / '>', record.seq() the bases as written
 // (case kept: the aligner upper-cases on the device, the writer echoes the
-// original), record.qual() the quality line.  Plain or gzip input (zlib).
+// original), record.qual() the quality line.  Plain or gzip input (io_inflate.cpp).
 #include <fcntl.h>
 #include <unistd.h>
-#include <zlib.h>
 
 #include <algorithm>
 #include <cerrno>
@@ -18,8 +17,8 @@
 #include "thermite_internal.h"
 
 struct thm_fastq {
-  gzFile f = nullptr;  // gzip input
-  int fd = -1;         // plain input: read(2) straight into the line buffer
+  thm::GzInflater* z = nullptr;  // gzip input (io_inflate.cpp)
+  int fd = -1;                   // plain input: read(2) straight into the line buffer
   std::string path;
   std::vector<char> buf;  // lines are handed out as views into this buffer (no per-line copies)
   size_t pos = 0, end = 0;
@@ -30,6 +29,50 @@ struct thm_fastq {
   std::string pending;  // a FASTA header read ahead while collecting sequence lines
   bool have_pending = false;
   thm::HostBatch own;  // storage behind thm_fastq_next_batch's view
+
+  // More bytes behind [pos, end); false when none came (end of the input, or an error: io_err).  The unread tail
+  // moves to the front of the buffer -- for gzip input together with the 32 KiB before `end`, which the matches of
+  // the bytes to come may reach back into.
+  bool fill_more() {
+    if (eof) return false;
+    constexpr size_t WINDOW = 32768;
+    const size_t keep_from = z ? std::min(pos, end > WINDOW ? end - WINDOW : (size_t)0) : pos;
+    if (keep_from > 0) {
+      memmove(buf.data(), buf.data() + keep_from, end - keep_from);
+      pos -= keep_from;
+      end -= keep_from;
+    }
+    if (buf.size() - end < (1u << 16)) buf.resize(buf.size() * 2);
+    const size_t room = std::min<size_t>(buf.size() - end, 1u << 30);
+    long n;
+    if (z) {
+      // a corrupt or truncated stream is an error of the inflater, never a short count
+      n = z->read((uint8_t*)buf.data() + end, room, std::min(end, WINDOW));
+      if (n < 0) {
+        io_err = true;
+        io_msg = z->error();
+        eof = true;
+      } else if (n == 0) {
+        eof = true;
+      } else if (!z->error().empty()) {  // the bytes inflated before an error come first; the error is already known
+        io_err = true;
+        io_msg = z->error();
+        eof = true;
+      }
+    } else {
+      do n = (long)read(fd, buf.data() + end, room);
+      while (n < 0 && errno == EINTR);
+      if (n < 0) {
+        io_err = true;
+        io_msg = "read error in " + path + ": " + strerror(errno);
+        eof = true;
+      } else if (n == 0) {
+        eof = true;
+      }
+    }
+    if (n > 0) end += (size_t)n;
+    return n > 0;
+  }
 
   // Next line without its terminator ('\n' or "\r\n") as a view valid until the next call.
   bool next_line(const char*& p, size_t& len) {
@@ -52,37 +95,7 @@ struct thm_fastq {
         while (len && p[len - 1] == '\r') len--;
         return true;
       }
-      // keep the partial line, refill behind it
-      if (pos > 0) {
-        memmove(buf.data(), buf.data() + pos, end - pos);
-        end -= pos;
-        pos = 0;
-      }
-      if (end == buf.size()) buf.resize(buf.size() * 2);
-      const size_t room = std::min<size_t>(buf.size() - end, 1u << 30);
-      const long n = f ? (long)gzread(f, buf.data() + end, (unsigned)room) : (long)read(fd, buf.data() + end, room);
-      if (n > 0) end += (size_t)n;
-      if (f) {
-        // a corrupt stream returns -1; a truncated one a short count and then 0 with Z_BUF_ERROR
-        if (n < (long)room) {
-          int zerr = Z_OK;
-          const char* zmsg = gzerror(f, &zerr);
-          if (n < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) {
-            io_err = true;
-            io_msg = "gzip read error in " + path + ": " + (zmsg && *zmsg ? zmsg : "corrupt or truncated stream");
-            eof = true;
-          } else if (n == 0) {
-            eof = true;
-          }
-        }
-      } else if (n < 0) {
-        if (errno == EINTR) continue;
-        io_err = true;
-        io_msg = "read error in " + path + ": " + strerror(errno);
-        eof = true;
-      } else if (n == 0) {
-        eof = true;
-      }
+      fill_more();  // keeps the partial line, reads behind it
     }
   }
 };
@@ -184,47 +197,7 @@ static int fastq_fill_raw(thm_fastq* r, uint64_t max_reads, HostBatch& b, size_t
 // ---- block cutting and block parsing for the parallel driver ----
 const std::string& fastq_path(const thm_fastq* r) { return r->path; }
 
-static bool refill(thm_fastq* r) {  // more bytes behind [pos, end); false at the end of the input
-  if (r->eof) return false;
-  const char* p;
-  size_t len;
-  // next_line's refill logic, without consuming a line: ask for a line only when none is buffered
-  const size_t before = r->end - r->pos;
-  // keep the unread tail, read behind it
-  if (r->pos > 0) {
-    memmove(r->buf.data(), r->buf.data() + r->pos, r->end - r->pos);
-    r->end -= r->pos;
-    r->pos = 0;
-  }
-  if (r->end == r->buf.size()) r->buf.resize(r->buf.size() * 2);
-  const size_t room = std::min<size_t>(r->buf.size() - r->end, 1u << 30);
-  const long n = r->f ? (long)gzread(r->f, r->buf.data() + r->end, (unsigned)room) : (long)read(r->fd, r->buf.data() + r->end, room);
-  if (n > 0) r->end += (size_t)n;
-  if (r->f) {
-    if (n < (long)room) {
-      int zerr = Z_OK;
-      const char* zmsg = gzerror(r->f, &zerr);
-      if (n < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) {
-        r->io_err = true;
-        r->io_msg = "gzip read error in " + r->path + ": " + (zmsg && *zmsg ? zmsg : "corrupt or truncated stream");
-        r->eof = true;
-      } else if (n == 0) {
-        r->eof = true;
-      }
-    }
-  } else if (n < 0) {
-    if (errno != EINTR) {
-      r->io_err = true;
-      r->io_msg = "read error in " + r->path + ": " + strerror(errno);
-      r->eof = true;
-    }
-  } else if (n == 0) {
-    r->eof = true;
-  }
-  (void)p;
-  (void)len;
-  return (r->end - r->pos) > before;
-}
+static bool refill(thm_fastq* r) { return r->fill_more(); }  // more bytes behind [pos, end); false at the end of the input
 
 bool fastq_is_plain_fastq(thm_fastq* r) {
   while (r->pos == r->end && refill(r)) {
@@ -362,19 +335,14 @@ int32_t thm_fastq_open(const char* path, thm_fastq** out) {
   if (fd < 0) return fail(THM_ERR_IO, std::string("cannot open ") + path);
   unsigned char magic[2] = {0, 0};
   const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-  gzFile f = nullptr;
-  if (gz) {
-    f = gzdopen(fd, "rb");
-    if (!f) {
-      close(fd);
-      return fail(THM_ERR_IO, std::string("cannot open ") + path);
-    }
-    gzbuffer(f, 1 << 20);
-  }
   thm_fastq* r = new thm_fastq();
-  r->f = f;
-  r->fd = gz ? -1 : fd;
   r->path = path;
+  if (gz) {
+    r->z = new thm::GzInflater();
+    r->z->open(fd, r->path);
+  } else {
+    r->fd = fd;
+  }
   r->buf.resize(8 << 20);
   *out = r;
   return THM_OK;
@@ -382,7 +350,7 @@ int32_t thm_fastq_open(const char* path, thm_fastq** out) {
 
 void thm_fastq_close(thm_fastq* r) {
   if (!r) return;
-  if (r->f) gzclose(r->f);
+  delete r->z;
   if (r->fd >= 0) close(r->fd);
   delete r;
 }
@@ -393,7 +361,7 @@ int32_t thm_debug_fastq_blocks(thm_fastq* r, uint64_t max_reads_per_block, thm_r
   if (!r || !out) return THM_ERR_INVALID_ARG;
   thm::HostBatch& all = r->own;
   all.clear();
-  if (!thm::fastq_is_plain_fastq(r)) return fail(THM_ERR_FORMAT, "not a plain FASTQ input");
+  if (!thm::fastq_is_plain_fastq(r)) return r->io_err ? fail(THM_ERR_IO, r->io_msg) : fail(THM_ERR_FORMAT, "not a plain FASTQ input");
   std::vector<char> raw;
   thm::HostBatch b;
   for (;;) {

@@ -1,0 +1,730 @@
+// io_inflate.cpp -- gzip (RFC 1952) / DEFLATE (RFC 1951) reader for the FASTQ batcher.
+//
+// The reference reads its query files through needletail::parse_fastx_file (reference src/aligner.rs:51-52), which
+// hands `.gz` input to flate2.  Nothing of that crate is restated here: this is a table-driven inflate written for
+// the one job the batcher has -- turn a gzip file into bytes as fast as one host thread can, so that inflating is
+// not what the GPU waits for.  What makes it quick:
+//   * a 64-bit bit buffer refilled with one unaligned 8-byte load (no per-byte loop);
+//   * an 11-bit first-level literal/length table whose entries hold the symbol AND the bit count, with up to FOUR
+//     literals in one entry where their codes fit the 11 bits together (FASTQ bases are 2- to 3-bit codes);
+//   * length base / extra-bit count folded into the entry, so that a match costs two lookups and no further
+//     table;
+//   * 16-byte match copies that may overshoot (the caller's buffer has the slack), run fill for distance 1
+//     (quality lines);
+//   * CRC-32 by carry-less multiplication (PCLMULQDQ folding, the published Intel scheme) where the CPU has it.
+// Every member's CRC-32 and ISIZE are checked; a truncated or corrupt stream is an error, never a short input.
+#include <fcntl.h>
+#include <unistd.h>
+#include <zlib.h>  // crc32() for the tail bytes and for CPUs without PCLMULQDQ
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+
+#include "io_internal.h"
+#include "thermite_internal.h"
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#include <wmmintrin.h>
+#endif
+
+namespace thm {
+
+// ---- CRC-32 ----
+#if defined(__x86_64__)
+#define THM_CLMUL __attribute__((target("sse4.2,pclmul")))
+THM_CLMUL static inline __m128i ld128(const uint8_t* p) { return _mm_loadu_si128((const __m128i*)p); }
+// x folded forward over the constants' distance, plus the next data y
+THM_CLMUL static inline __m128i fold128(__m128i x, __m128i k, __m128i y) {
+  return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k, 0x00), _mm_clmulepi64_si128(x, k, 0x11)), y);
+}
+// len >= 64 and a multiple of 16; crc is the running register (i.e. already inverted)
+THM_CLMUL static uint32_t crc32_fold(const uint8_t* buf, size_t len, uint32_t crc) {
+  alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};  // x^(512+64), x^512 mod P (reflected)
+  alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};  // x^(128+64), x^128
+  alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0};                // x^64
+  alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};  // P and the Barrett constant
+  __m128i x0 = _mm_load_si128((const __m128i*)k1k2);
+  __m128i x1 = _mm_xor_si128(ld128(buf), _mm_cvtsi32_si128((int)crc)), x2 = ld128(buf + 16), x3 = ld128(buf + 32), x4 = ld128(buf + 48);
+  buf += 64;
+  len -= 64;
+  while (len >= 64) {
+    x1 = fold128(x1, x0, ld128(buf));
+    x2 = fold128(x2, x0, ld128(buf + 16));
+    x3 = fold128(x3, x0, ld128(buf + 32));
+    x4 = fold128(x4, x0, ld128(buf + 48));
+    buf += 64;
+    len -= 64;
+  }
+  x0 = _mm_load_si128((const __m128i*)k3k4);
+  x1 = fold128(x1, x0, x2);
+  x1 = fold128(x1, x0, x3);
+  x1 = fold128(x1, x0, x4);
+  while (len >= 16) {
+    x1 = fold128(x1, x0, ld128(buf));
+    buf += 16;
+    len -= 16;
+  }
+  // 128 -> 64 -> 32 bits, then Barrett reduction
+  const __m128i m32 = _mm_setr_epi32(~0, 0, ~0, 0);
+  x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+  x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), x2);
+  x0 = _mm_loadl_epi64((const __m128i*)k5k0);
+  x2 = _mm_srli_si128(x1, 4);
+  x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, m32), x0, 0x00), x2);
+  x0 = _mm_load_si128((const __m128i*)poly);
+  x2 = _mm_and_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, m32), x0, 0x10), m32);
+  x1 = _mm_xor_si128(x1, _mm_clmulepi64_si128(x2, x0, 0x00));
+  return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+static const bool have_clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.2");
+#endif
+
+uint32_t crc32_fast(uint32_t crc, const uint8_t* p, size_t n) {
+#if defined(__x86_64__)
+  if (have_clmul && n >= 64) {
+    const size_t m = n & ~(size_t)15;
+    crc = ~crc32_fold(p, m, ~crc);
+    p += m;
+    n -= m;
+  }
+#endif
+  while (n) {
+    const unsigned k = (unsigned)(n > (1u << 30) ? (1u << 30) : n);
+    crc = (uint32_t)crc32(crc, p, k);
+    p += k;
+    n -= k;
+  }
+  return crc;
+}
+
+// ---- tables ----
+// Entry layout (u32), literal/length table:
+//   bits 0..7   bits to take off the bit buffer (code length, plus the extra bits of a length code)
+//   bits 8..11  code length (length codes only: the extra bits start there)
+//   bit  12     exceptional: end of block (payload 0), sub-table (payload = first entry, bits 0..7 = index bits of
+//               the sub-table, bits 8..11 = 0) or invalid code (payload 0xFFFF)
+//   bit  15     literal
+//   bits 16..31 payload: literal, or length base, or sub-table start
+// Distance table: same, payload = distance base, never literals.
+namespace {
+constexpr int LIT_BITS = 11, DIST_BITS = 8;
+constexpr uint32_t E_LIT = 1u << 15, E_EXC = 1u << 12;
+constexpr uint32_t E_INVALID = E_EXC | (0xFFFFu << 16) | 1u, E_EOB_PAYLOAD = 0;
+// room for every sub-table any valid code can ask for (one of at most 2^4 / 2^7 entries per long symbol)
+constexpr int MAX_LIT_ENTRIES = (1 << LIT_BITS) + 286 * 16, MAX_DIST_ENTRIES = (1 << DIST_BITS) + 30 * 128;
+
+const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+inline uint32_t bitrev(uint32_t c, int n) {
+  uint32_t r = 0;
+  for (int i = 0; i < n; i++) r |= ((c >> i) & 1u) << (n - 1 - i);
+  return r;
+}
+
+// symbol -> entry without the bit count
+inline uint32_t lit_entry(int sym, int len) {
+  if (sym < 256) return E_LIT | ((uint32_t)sym << 16) | (uint32_t)len;
+  if (sym == 256) return E_EXC | (E_EOB_PAYLOAD << 16) | (uint32_t)len;
+  if (sym > 285) return E_INVALID;
+  const int k = sym - 257;
+  return ((uint32_t)len_base[k] << 16) | ((uint32_t)len << 8) | (uint32_t)(len + len_extra[k]);
+}
+inline uint32_t dist_entry(int sym, int len) {
+  if (sym > 29) return E_INVALID;
+  return ((uint32_t)dist_base[sym] << 16) | ((uint32_t)len << 8) | (uint32_t)(len + dist_extra[sym]);
+}
+
+// Canonical Huffman decoding table from code lengths (0 = unused).  false: over-subscribed, or no room for the
+// sub-tables.  An incomplete code leaves invalid entries behind (reported when the stream walks into one).
+template <class MakeEntry>
+bool build_table(const uint8_t* lens, int n_sym, int table_bits, uint32_t* table, int max_entries, MakeEntry make) {
+  int count[16] = {0};
+  for (int i = 0; i < n_sym; i++) count[lens[i]]++;
+  count[0] = 0;
+  int left = 1;
+  for (int l = 1; l <= 15; l++) {
+    left = (left << 1) - count[l];
+    if (left < 0) return false;
+  }
+  uint32_t next[16];
+  uint32_t code = 0;
+  for (int l = 1; l <= 15; l++) {
+    code = (code + (uint32_t)count[l - 1]) << 1;
+    next[l] = code;
+  }
+  const int primary = 1 << table_bits;
+  for (int i = 0; i < primary; i++) table[i] = E_INVALID;
+  int used = primary;
+  // sub-tables: one per distinct table_bits-bit prefix (reversed: the LOW table_bits bits of the reversed code); the
+  // codes of a prefix are consecutive in canonical order, so each sub-table is sized by the longest code under it
+  // first pass: longest code per prefix
+  uint8_t sub_bits[1 << LIT_BITS];
+  bool any_long = false;
+  for (int l = table_bits + 1; l <= 15; l++) any_long |= count[l] != 0;
+  if (any_long) {
+    memset(sub_bits, 0, (size_t)primary);
+    uint32_t nx[16];
+    memcpy(nx, next, sizeof nx);
+    for (int s = 0; s < n_sym; s++) {
+      const int l = lens[s];
+      if (l <= table_bits) {
+        if (l) nx[l]++;
+        continue;
+      }
+      const uint32_t r = bitrev(nx[l]++, l), pre = r & (uint32_t)(primary - 1);
+      if (l - table_bits > sub_bits[pre]) sub_bits[pre] = (uint8_t)(l - table_bits);
+    }
+    for (int pre = 0; pre < primary; pre++)
+      if (sub_bits[pre]) {
+        const int n = 1 << sub_bits[pre];
+        if (used + n > max_entries) return false;
+        table[pre] = E_EXC | ((uint32_t)used << 16) | (uint32_t)sub_bits[pre];
+        for (int i = 0; i < n; i++) table[used + i] = E_INVALID;
+        used += n;
+      }
+  }
+  for (int s = 0; s < n_sym; s++) {
+    const int l = lens[s];
+    if (!l) continue;
+    const uint32_t r = bitrev(next[l]++, l);
+    if (l <= table_bits) {
+      const uint32_t e = make(s, l);
+      for (uint32_t i = r; i < (uint32_t)primary; i += 1u << l) table[i] = e;
+    } else {
+      const uint32_t pre = r & (uint32_t)(primary - 1), top = table[pre];
+      const int sb = (int)(top & 0xFF), l2 = l - table_bits;
+      uint32_t* sub = table + (top >> 16);
+      // the entry's bit count is that of the whole code: the sub-table lookup happens on the un-shifted buffer
+      const uint32_t e = make(s, l);
+      for (uint32_t i = r >> table_bits; i < (1u << sb); i += 1u << l2) sub[i] = e;
+    }
+  }
+  return true;
+}
+
+// The first-level table the hot loop reads: 64-bit entries, the low half as above, and for literals up to FOUR of
+// them in the high half (count in bits 8..10, bits 0..7 the sum of their code lengths) -- as many whole literal
+// codes as the 11 index bits hold.  FASTQ is mostly literals with 2- to 4-bit codes.
+void group_literals(const uint32_t* single, uint64_t* table) {
+  for (uint32_t i = 0; i < (1u << LIT_BITS); i++) {
+    const uint32_t e = single[i];
+    if (!(e & E_LIT)) {
+      table[i] = e;
+      continue;
+    }
+    int bits = 0, count = 0;
+    uint64_t lits = 0;
+    while (count < 4) {
+      const uint32_t e1 = single[i >> bits];  // (the index bits above the code are zero: any code they complete is too long)
+      const int l = (int)(e1 & 0xFF);
+      if (!(e1 & E_LIT) || bits + l > LIT_BITS) break;
+      lits |= (uint64_t)((e1 >> 16) & 0xFF) << (8 * count);
+      count++;
+      bits += l;
+    }
+    table[i] = (uint64_t)(E_LIT | ((uint32_t)count << 8) | (uint32_t)bits) | (lits << 32);
+  }
+}
+
+inline uint64_t load64(const uint8_t* p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;
+}
+}  // namespace
+
+struct GzInflater::Impl {
+  int fd = -1;
+  std::string path;
+  std::vector<uint8_t> in;  // compressed bytes [ipos, iend), then IN_PAD zero bytes once the file has ended
+  size_t ipos = 0, iend = 0;
+  bool in_eof = false;
+  uint64_t bitbuf = 0;
+  int bitcnt = 0;
+  enum State { MEMBER_HEADER, BLOCK_HEADER, STORED, HUFFMAN, TRAILER, END } state = MEMBER_HEADER;
+  bool last_block = false;
+  uint32_t stored_left = 0;
+  uint32_t crc = 0;
+  uint64_t member_out = 0;  // bytes of the current member (ISIZE is this modulo 2^32)
+  uint64_t total_out = 0;
+  uint64_t n_members = 0;
+  uint32_t lit[MAX_LIT_ENTRIES], dist[MAX_DIST_ENTRIES];
+  uint64_t lit4[1 << LIT_BITS];  // what the hot loop reads first (group_literals)
+  bool fixed_loaded = false;
+  std::string err;
+
+  static constexpr size_t IN_CAP = 4u << 20, IN_PAD = 64;
+
+  // at least `want` compressed bytes behind ipos, unless the file ends first (then zero padding stands behind iend)
+  void fill(size_t want) {
+    while (iend - ipos < want && !in_eof) {
+      if (ipos > 0) {
+        memmove(in.data(), in.data() + ipos, iend - ipos);
+        iend -= ipos;
+        ipos = 0;
+      }
+      const long n = ::read(fd, in.data() + iend, IN_CAP - iend);
+      if (n < 0) {
+        if (errno == EINTR) continue;
+        err = "read error in " + path + ": " + strerror(errno);
+        in_eof = true;
+      } else if (n == 0) {
+        in_eof = true;
+      } else {
+        iend += (size_t)n;
+      }
+      if (in_eof) memset(in.data() + iend, 0, IN_PAD);
+    }
+  }
+  // the bit reader's position as a byte position (whole bytes still in the bit buffer are handed back)
+  void align_to_byte() {
+    const int drop = bitcnt & 7;
+    bitbuf >>= drop;
+    bitcnt -= drop;
+    ipos -= (size_t)(bitcnt >> 3);
+    bitbuf = 0;
+    bitcnt = 0;
+  }
+  bool bytes(size_t n) {  // n more compressed bytes present at ipos
+    fill(n);
+    return iend - ipos >= n;
+  }
+  bool fail(const std::string& what) {
+    if (err.empty()) err = "gzip read error in " + path + ": " + what;
+    return false;
+  }
+
+  bool member_header() {
+    // between members: zero padding / nothing means the end
+    if (!bytes(1)) {
+      if (n_members == 0) return fail("empty file");
+      state = END;
+      return true;
+    }
+    if (!bytes(10)) return fail("truncated stream");
+    const uint8_t* h = in.data() + ipos;
+    if (h[0] != 0x1f || h[1] != 0x8b) {
+      if (n_members == 0) return fail("not a gzip stream");
+      // bytes behind the last member that are not a member: zlib's gzread ignores them ("trailing garbage")
+      state = END;
+      return true;
+    }
+    if (h[2] != 8) return fail("unknown compression method");
+    const int flg = h[3];
+    if (flg & 0xE0) return fail("reserved header flags set");
+    ipos += 10;
+    if (flg & 4) {  // FEXTRA
+      if (!bytes(2)) return fail("truncated stream");
+      const size_t xlen = in[ipos] | ((size_t)in[ipos + 1] << 8);
+      ipos += 2;
+      if (!bytes(xlen)) return fail("truncated stream");
+      ipos += xlen;
+    }
+    for (int f = 8; f <= 16; f <<= 1)  // FNAME, FCOMMENT: zero-terminated
+      if (flg & f) {
+        for (;;) {
+          if (!bytes(1)) return fail("truncated stream");
+          if (in[ipos++] == 0) break;
+        }
+      }
+    if (flg & 2) {  // FHCRC
+      if (!bytes(2)) return fail("truncated stream");
+      ipos += 2;
+    }
+    crc = 0;
+    member_out = 0;
+    n_members++;
+    state = BLOCK_HEADER;
+    return true;
+  }
+
+  // plain bit reading for the block headers (never the hot loop)
+  bool need_bits(int n) {
+    while (bitcnt < n) {
+      if (!bytes(1)) return fail("truncated stream");
+      bitbuf |= (uint64_t)in[ipos++] << bitcnt;
+      bitcnt += 8;
+    }
+    return true;
+  }
+  uint32_t take(int n) {
+    const uint32_t v = (uint32_t)(bitbuf & ((1ull << n) - 1));
+    bitbuf >>= n;
+    bitcnt -= n;
+    return v;
+  }
+
+  bool block_header() {
+    if (!need_bits(3)) return false;
+    last_block = take(1) != 0;
+    const uint32_t type = take(2);
+    if (type == 0) {
+      align_to_byte();
+      if (!bytes(4)) return fail("truncated stream");
+      const uint32_t len = in[ipos] | ((uint32_t)in[ipos + 1] << 8), nlen = in[ipos + 2] | ((uint32_t)in[ipos + 3] << 8);
+      if ((len ^ 0xFFFFu) != nlen) return fail("invalid stored block lengths");
+      ipos += 4;
+      stored_left = len;
+      state = STORED;
+      return true;
+    }
+    if (type == 1) {
+      uint8_t l[288 + 32];
+      int i = 0;
+      for (; i < 144; i++) l[i] = 8;
+      for (; i < 256; i++) l[i] = 9;
+      for (; i < 280; i++) l[i] = 7;
+      for (; i < 288; i++) l[i] = 8;
+      build_table(l, 288, LIT_BITS, lit, MAX_LIT_ENTRIES, lit_entry);
+      group_literals(lit, lit4);
+      for (i = 0; i < 32; i++) l[i] = 5;
+      build_table(l, 32, DIST_BITS, dist, MAX_DIST_ENTRIES, dist_entry);
+      state = HUFFMAN;
+      return true;
+    }
+    if (type == 3) return fail("invalid block type");
+    if (!need_bits(14)) return false;
+    const int hlit = (int)take(5) + 257, hdist = (int)take(5) + 1, hclen = (int)take(4) + 4;
+    if (hlit > 286 || hdist > 30) return fail("too many length or distance symbols");
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19] = {0};
+    for (int i = 0; i < hclen; i++) {
+      if (!need_bits(3)) return false;
+      cl[order[i]] = (uint8_t)take(3);
+    }
+    uint32_t clt[128 + 8];
+    if (!build_table(cl, 19, 7, clt, 128, [](int s, int l) { return ((uint32_t)s << 16) | (uint32_t)l; }))
+      return fail("invalid code lengths set");
+    uint8_t lens[286 + 30 + 138];
+    int n = 0;
+    while (n < hlit + hdist) {
+      if (!need_bits(7 + 7)) return false;  // (a block's end-of-block code and the member trailer always follow)
+      const uint32_t e = clt[bitbuf & 127];
+      if (e == E_INVALID) return fail("invalid code lengths set");
+      const int l = (int)(e & 0xFF), sym = (int)(e >> 16);
+      if (l > bitcnt) return fail("truncated stream");
+      take(l);
+      if (sym < 16) {
+        lens[n++] = (uint8_t)sym;
+        continue;
+      }
+      int rep, val = 0;
+      if (sym == 16) {
+        if (n == 0) return fail("invalid bit length repeat");
+        if (bitcnt < 2) return fail("truncated stream");
+        val = lens[n - 1];
+        rep = 3 + (int)take(2);
+      } else if (sym == 17) {
+        if (bitcnt < 3) return fail("truncated stream");
+        rep = 3 + (int)take(3);
+      } else {
+        if (bitcnt < 7) return fail("truncated stream");
+        rep = 11 + (int)take(7);
+      }
+      if (n + rep > hlit + hdist) return fail("invalid bit length repeat");
+      memset(lens + n, val, (size_t)rep);
+      n += rep;
+    }
+    if (lens[256] == 0) return fail("invalid code -- missing end-of-block");
+    if (!build_table(lens, hlit, LIT_BITS, lit, MAX_LIT_ENTRIES, lit_entry)) return fail("invalid literal/lengths set");
+    group_literals(lit, lit4);
+    if (!build_table(lens + hlit, hdist, DIST_BITS, dist, MAX_DIST_ENTRIES, dist_entry)) return fail("invalid distances set");
+    state = HUFFMAN;
+    return true;
+  }
+
+  // The hot loop.  Runs while `out` is at least OUT_SLACK bytes below `out_end`; returns with the state moved on at
+  // the end of the block, or unchanged when the output is full.  `floor` is the lowest address a match may reach.
+  static constexpr size_t OUT_SLACK = 320;
+  bool huffman(uint8_t*& out_io, uint8_t* out_end, const uint8_t* floor) {
+    uint8_t* out = out_io;
+    uint8_t* const out_stop = out_end - OUT_SLACK;
+    uint64_t bb = bitbuf;
+    int bc = bitcnt;
+    const uint8_t* ip = in.data() + ipos;
+    const uint8_t* ip_safe = in.data() + iend - (in_eof ? 0 : 32);  // past this: fetch more of the file first
+    // at the end of the file the zero padding lets the loop read on; `ip_limit` is how far a valid stream can get
+    const uint8_t* ip_limit = in.data() + iend + 8;
+    const uint32_t* const lt = lit;
+    const uint64_t* const l4 = lit4;
+    const uint32_t* const dt = dist;
+    bool ok = true;
+    auto refill = [&] {
+      bb |= load64(ip) << bc;
+      ip += (63 - bc) >> 3;
+      bc |= 56;
+    };
+    for (;;) {
+      if (out >= out_stop) break;
+      if (ip > ip_safe) {
+        if (!in_eof) {
+          // hand the position back, fetch, and go on
+          ipos = (size_t)(ip - in.data());
+          fill(IN_CAP / 2);
+          if (!err.empty()) {
+            ok = false;
+            break;
+          }
+          ip = in.data() + ipos;
+          ip_safe = in.data() + iend - (in_eof ? 0 : 32);
+          ip_limit = in.data() + iend + 8;
+          continue;
+        }
+        // the bits taken so far must all have come out of the file (ip runs up to 8 bytes ahead of them)
+        if (ip > ip_limit || (int64_t)(ip - in.data()) * 8 - bc > (int64_t)iend * 8) {
+          ok = fail("truncated stream");
+          break;
+        }
+      }
+      refill();
+      uint64_t e4 = l4[bb & ((1u << LIT_BITS) - 1)];
+      // up to three table entries of literals per refill (3 x 11 bits at most)
+      auto put_literals = [&] {
+        const uint32_t v = (uint32_t)(e4 >> 32);
+        memcpy(out, &v, 4);
+        out += (e4 >> 8) & 7;
+        bb >>= (e4 & 0xFF);
+        bc -= (int)(e4 & 0xFF);
+        e4 = l4[bb & ((1u << LIT_BITS) - 1)];
+      };
+      if (e4 & E_LIT) {
+        put_literals();
+        if (e4 & E_LIT) {
+          put_literals();
+          if (e4 & E_LIT) {
+            const uint32_t v = (uint32_t)(e4 >> 32);
+            memcpy(out, &v, 4);
+            out += (e4 >> 8) & 7;
+            bb >>= (e4 & 0xFF);
+            bc -= (int)(e4 & 0xFF);
+            continue;
+          }
+        }
+        // at least 56 - 22 = 34 bits are left: enough for any literal/length code with its extra bits (20)
+      }
+      uint32_t e = (uint32_t)e4;
+      if (e & E_EXC) {
+        if ((e >> 16) == 0xFFFF) {
+          ok = fail("invalid literal/length code");
+          break;
+        }
+        if ((e >> 16) != 0) {  // sub-table (the end-of-block entry has payload 0)
+          e = lt[(e >> 16) + ((bb >> LIT_BITS) & ((1u << (e & 0xFF)) - 1))];
+          if (e & E_LIT) {
+            *out++ = (uint8_t)(e >> 16);
+            bb >>= (e & 0xFF);
+            bc -= (int)(e & 0xFF);
+            continue;
+          }
+          if ((e & E_EXC) && (e >> 16) == 0xFFFF) {
+            ok = fail("invalid literal/length code");
+            break;
+          }
+        }
+        if (e & E_EXC) {  // end of block
+          bb >>= (e & 0xFF);
+          bc -= (int)(e & 0xFF);
+          state = last_block ? TRAILER : BLOCK_HEADER;
+          break;
+        }
+      }
+      // a length: base + extra bits
+      const int cl = (int)((e >> 8) & 0xF), tot = (int)(e & 0xFF);
+      uint32_t len = (e >> 16) + (uint32_t)((bb >> cl) & ((1u << (tot - cl)) - 1));
+      bb >>= tot;
+      bc -= tot;
+      refill();
+      uint32_t d = dt[bb & ((1u << DIST_BITS) - 1)];
+      if (d & E_EXC) {
+        if ((d >> 16) == 0xFFFF) {
+          ok = fail("invalid distance code");
+          break;
+        }
+        d = dt[(d >> 16) + ((bb >> DIST_BITS) & ((1u << (d & 0xFF)) - 1))];
+        if (d & E_EXC) {
+          ok = fail("invalid distance code");
+          break;
+        }
+      }
+      const int dcl = (int)((d >> 8) & 0xF), dtot = (int)(d & 0xFF);
+      const uint32_t distance = (d >> 16) + (uint32_t)((bb >> dcl) & ((1u << (dtot - dcl)) - 1));
+      bb >>= dtot;
+      bc -= dtot;
+      if ((size_t)(out - floor) < distance) {
+        ok = fail("invalid distance too far back");
+        break;
+      }
+      const uint8_t* src = out - distance;
+      uint8_t* const oe = out + len;
+      if (distance >= 16) {
+        do {
+          memcpy(out, src, 16);
+          out += 16;
+          src += 16;
+        } while (out < oe);
+      } else if (distance == 1) {
+        memset(out, *src, len);
+      } else if (distance >= 8) {
+        do {
+          memcpy(out, src, 8);
+          out += 8;
+          src += 8;
+        } while (out < oe);
+      } else {
+        do *out++ = *src++;
+        while (out < oe);
+      }
+      out = oe;
+    }
+    bitbuf = bb;
+    bitcnt = bc;
+    ipos = (size_t)(ip - in.data());
+    out_io = out;
+    return ok;
+  }
+};
+
+GzInflater::GzInflater() : p_(new Impl()) {}
+GzInflater::~GzInflater() {
+  if (p_->fd >= 0) close(p_->fd);
+  delete p_;
+}
+void GzInflater::open(int fd, const std::string& path) {
+  p_->fd = fd;
+  p_->path = path;
+  p_->in.resize(Impl::IN_CAP + Impl::IN_PAD);
+}
+const std::string& GzInflater::error() const { return p_->err; }
+
+long GzInflater::read(uint8_t* dst, size_t cap, size_t history) {
+  Impl& s = *p_;
+  if (!s.err.empty()) return -1;
+  if (cap < 2 * Impl::OUT_SLACK) {
+    s.err = "internal: inflate buffer too small";
+    return -1;
+  }
+  uint8_t* out = dst;
+  uint8_t* const out_end = dst + cap;
+  // a match reaches back into this member's output only
+  const uint8_t* floor = dst - (s.state == Impl::MEMBER_HEADER || s.state == Impl::END ? 0 : std::min<uint64_t>(history, s.member_out));
+  const uint8_t* crc_from = dst;
+  auto crc_upto = [&](const uint8_t* upto) {
+    s.crc = crc32_fast(s.crc, crc_from, (size_t)(upto - crc_from));
+    s.member_out += (uint64_t)(upto - crc_from);
+    crc_from = upto;
+  };
+  bool ok = true;
+  while (ok && s.state != Impl::END && out < out_end - Impl::OUT_SLACK) {
+    switch (s.state) {
+      case Impl::MEMBER_HEADER:
+        ok = s.member_header();
+        // a member's matches must not reach into the member before it
+        if (ok && s.state == Impl::BLOCK_HEADER) floor = out;
+        break;
+      case Impl::BLOCK_HEADER:
+        ok = s.block_header();
+        break;
+      case Impl::STORED: {
+        size_t n = std::min<size_t>(s.stored_left, (size_t)(out_end - out));
+        s.fill(std::min<size_t>(n, Impl::IN_CAP / 2));
+        n = std::min(n, s.iend - s.ipos);
+        if (n == 0 && s.stored_left) {
+          ok = s.fail("truncated stream");
+          break;
+        }
+        memcpy(out, s.in.data() + s.ipos, n);
+        out += n;
+        s.ipos += n;
+        s.stored_left -= (uint32_t)n;
+        if (s.stored_left == 0) s.state = s.last_block ? Impl::TRAILER : Impl::BLOCK_HEADER;
+        break;
+      }
+      case Impl::HUFFMAN:
+        ok = s.huffman(out, out_end, floor);
+        if (ok && !s.err.empty()) ok = false;
+        break;
+      case Impl::TRAILER: {
+        s.align_to_byte();
+        if (s.ipos > s.iend) {
+          ok = s.fail("truncated stream");
+          break;
+        }
+        if (!s.bytes(8)) {
+          ok = s.fail("truncated stream");
+          break;
+        }
+        crc_upto(out);
+        const uint8_t* t = s.in.data() + s.ipos;
+        const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t want_len = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if (want_crc != s.crc) {
+          ok = s.fail("incorrect data check");
+          break;
+        }
+        if (want_len != (uint32_t)s.member_out) {
+          ok = s.fail("incorrect length check");
+          break;
+        }
+        s.ipos += 8;
+        s.state = Impl::MEMBER_HEADER;
+        break;
+      }
+      case Impl::END:
+        break;
+    }
+  }
+  if (!ok || !s.err.empty()) {
+    if (s.err.empty()) s.err = "gzip read error in " + s.path;
+    // what was inflated before the error is handed over first (a stream's bytes, then its error: the next call fails)
+    if (out == dst) return -1;
+    s.total_out += (uint64_t)(out - dst);
+    return (long)(out - dst);
+  }
+  if (s.state != Impl::END) crc_upto(out);
+  s.total_out += (uint64_t)(out - dst);
+  return (long)(out - dst);
+}
+
+}  // namespace thm
+
+// test hook: the whole gzip file through GzInflater in calls of `chunk` bytes (so that matches, stored blocks and
+// members straddle calls); *n_out bytes land in out[0, cap).  THM_ERR_IO with the inflater's message on a bad stream.
+extern "C" int32_t thm_debug_gunzip(const char* path, uint64_t chunk, uint8_t* out, uint64_t cap, uint64_t* n_out) {
+  if (!path || !out || !n_out || chunk < 1024) return THM_ERR_INVALID_ARG;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) {
+    thm::set_global_error(std::string("cannot open ") + path);
+    return THM_ERR_IO;
+  }
+  thm::GzInflater z;
+  z.open(fd, path);
+  constexpr size_t W = 32768;
+  std::vector<uint8_t> buf(W + chunk);
+  size_t hist = 0;
+  uint64_t total = 0;
+  for (;;) {
+    const long n = z.read(buf.data() + W, chunk, hist);
+    if (n < 0) {
+      *n_out = total;
+      thm::set_global_error(z.error());
+      return THM_ERR_IO;
+    }
+    if (n == 0) break;
+    if (total + (uint64_t)n > cap) {
+      thm::set_global_error("thm_debug_gunzip: output buffer too small");
+      return THM_ERR_INVALID_ARG;
+    }
+    memcpy(out + total, buf.data() + W, (size_t)n);
+    total += (uint64_t)n;
+    const size_t have = hist + (size_t)n, keep = std::min(have, W);
+    memmove(buf.data() + W - keep, buf.data() + W + (size_t)n - keep, keep);
+    hist = keep;
+  }
+  *n_out = total;
+  return THM_OK;
+}

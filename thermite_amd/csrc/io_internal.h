@@ -53,6 +53,26 @@ int fastq_parse_block(const char* p, size_t n, const std::string& path, uint64_t
                       std::string& err);
 const std::string& fastq_path(const thm_fastq* r);
 
+// gzip input (io_inflate.cpp): a table-driven inflate with CRC-32 / ISIZE checks per member
+uint32_t crc32_fast(uint32_t crc, const uint8_t* p, size_t n);
+class GzInflater {
+ public:
+  GzInflater();
+  ~GzInflater();
+  GzInflater(const GzInflater&) = delete;
+  GzInflater& operator=(const GzInflater&) = delete;
+  void open(int fd, const std::string& path);  // takes the descriptor over
+  // Up to `cap` further bytes of the inflated stream into dst (cap >= 1024; the call stops a few hundred bytes short
+  // of cap rather than in the middle of a match).  dst[-history, 0) must hold the `history` bytes that came before
+  // (min(bytes so far, 32768) of them: matches reach back there).  0: end of the input; -1: error().
+  long read(uint8_t* dst, size_t cap, size_t history);
+  const std::string& error() const;
+
+ private:
+  struct Impl;
+  Impl* p_;
+};
+
 // thm_writer_format_batch without the final concatenation: the text of the batch is
 // chunks[0] ++ chunks[1] ++ ... (one chunk per formatting thread, valid until the next call on `w`)
 int writer_format_chunks(thm_writer* w, const thm_read_batch* reads, const thm_batch_view* res,

@@ -13,6 +13,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -544,7 +545,15 @@ bool bgzf_compress(const char* p, size_t n, std::string& out) {
   // a tenth of the work), reset between the members
   z_stream zs;
   memset(&zs, 0, sizeof zs);
-  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  // Level 1 unless THM_BAM_LEVEL says otherwise: the records leave unsorted, for a sorter that rewrites them anyway,
+  // and at level 6 sixteen threads deflate some 3 M records a second -- a third of what the stages before deliver.
+  // (Parity is defined on the inflated stream: the compressed bytes depend on the deflate implementation as it is.)
+  static const int level = [] {
+    const char* e = getenv("THM_BAM_LEVEL");
+    const int v = e && *e ? atoi(e) : 1;
+    return v < 0 || v > 9 ? 1 : v;
+  }();
+  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
   bool ok = true;
   for (size_t off = 0; off < n || (n == 0 && off == 0); off += BLOCK) {
     const size_t len = std::min(BLOCK, n - off);
