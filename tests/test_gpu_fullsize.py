@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as orc
-from thermite_amd import capi, synth, validate
+from thermite_amd import capi, refdata, synth, validate
 
 from gpu_common import assert_batch_equal
 
@@ -87,3 +87,38 @@ def test_config5_shape_full_size(world):
     checked, bad = validate.check_batch(t, bases, off, g, max_alns=2000)
     assert checked == 2000 and not bad, bad[:5]
     a.close()
+
+
+def test_full_size_wide_coordinates(world):
+    """the 64-bit-coordinate instantiation (what a text beyond 2^31 - 16 symbols selects) at full batch size: the same
+    500 000 reads through an index forced wide give the narrow index's records, which the test above pins to the oracle"""
+    t, sa, ix = world
+    n = 500000
+    bases, off, _ = synth.simulate_reads(t, n, 91, sub_rate=0.01, indel_rate=0.001, stream=100)
+    wide = capi.Index(t, sa=sa, wide=True)
+    assert wide.coord_bytes == 8 and ix.coord_bytes == 4
+    a = capi.Aligner(wide, capi.CI_OPTS)
+    g = a.align_batch(bases, off)
+    oix = orc.Index(t, sa=sa)
+    r = oix.align_batch(bases, off, capi.CI_OPTS, n_threads=16)
+    assert_batch_equal(g, r)
+    a.close()
+
+
+def test_config2_chrM_at_size(data_dir):
+    """BASELINE config 2's shape: 500 000 reads of 91 bp against the GRCh38-2020-A chrM transcriptome the reference's
+    own tests ship (16 569 bp, 37 genes: every read lands in the same few windows, so seed lists and candidate pools
+    are as contended as they get).  Exact parity with the oracle on every read, with the default options and with
+    the reference CI's (-k20 -s0 --intron-mode)."""
+    t = refdata.load_reference(data_dir + "/GRCh38-2020-A-chrM.fasta", data_dir + "/GRCh38-2020-A-chrM.gtf")
+    n = 500000
+    bases, off, _ = synth.simulate_reads(t, n, 91, sub_rate=0.01, indel_rate=0.001, stream=2, intronic_frac=0.25)
+    ix = capi.Index(t)
+    oix = orc.Index(t)
+    for opts in (capi.DEFAULT_OPTS, capi.CI_OPTS):
+        a = capi.Aligner(ix, opts)
+        g = a.align_batch(bases, off)
+        r = oix.align_batch(bases, off, opts, n_threads=16)
+        assert_batch_equal(g, r)
+        assert (np.diff(g.offsets.astype(np.int64)) > 0).mean() > (0.95 if opts is capi.CI_OPTS else 0.4)
+        a.close()

@@ -114,6 +114,7 @@ struct thm_aligner {
       s_work_counts, s_sel_scratch, s_heavy, s_slow, s_team;
   uint64_t smem_cap = 0;
   // extension
+  DBuf e_heavy, e_rel;  // compact stage: lists of reads with many alignments, op offsets of their alignments
   DBuf e_cands, e_order, e_ops, e_nalns, e_nalns64, e_opbytes, e_aln_off, e_ops_off, e_trace, e_slow, e_recs, e_wcnt;
   // Extension problems as the unit of wavefront work (kernels_tpr.hip: thread-per-read control kernel + wave-per-request
   // DP kernel, in rounds), ahead of the wave-per-read kernels, which take what is left.  THM_TPR=0 or

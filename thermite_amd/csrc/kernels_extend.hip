@@ -1800,77 +1800,204 @@ __global__ __launch_bounds__(1024) void counters_reduce_kernel(const unsigned lo
   }
 }
 
-// final layout: alignments of read r at alns[read_aln_off[r]..], op streams back
-// to back in the same order (gx ops, then tx ops of an exonic alignment)
-__global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
-  // 16 lanes per read (four reads per wavefront): the work per read is a chain of a few dependent
-  // loads and ~200 bytes of copying, so what counts is how many reads are in flight
-  const int sub = (int)(threadIdx.x & 15u);
-  const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-  if (r >= p.n_reads) return;
-  // a faulted attempt (pool overflow) is replayed by the host with larger pools: its counts and offsets are not to be trusted
-  if (p.fault[0] != 0 || (p.fault[1] & FAULT_OPS_POOL) != 0) return;
-  const uint32_t n = p.read_n_alns[r];
-  if (n == 0) return;
-  const uint64_t cand0 = p.read_cand_off[r];
-  const Cand* cands = p.cands + cand0;
-  const uint32_t* la = p.order + 2 * cand0;
-  const uint32_t xlen = (uint32_t)(p.read_offsets[r + 1] - p.read_offsets[r]);
-  uint64_t o = p.read_ops_off[r];
-  const uint64_t a0 = p.read_aln_off[r];
-  for (uint32_t t = 0; t < n; t++) {
-    const Cand cd = cands[la[t]];
-    if (a0 + t >= p.alns_cap || o + cd.ops_len + cd.tx_ops_len > p.ops_cap) return;  // never without a fault; keeps every store in bounds
-    // 64 bytes per step of the 16 lanes, the four loads of a lane in flight together (a byte at a time would be one
-    // memory round trip per 16 bytes)
-    auto copy_ops = [&](const uint8_t* src, uint8_t* dst, uint32_t len) {
-      #pragma unroll 1
-      for (uint32_t b0 = 0; b0 < len; b0 += 64) {
-        uint8_t v[4];
-        #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t b = b0 + (uint32_t)sub + 16u * (uint32_t)k;
-          v[k] = (b < len) ? src[b] : (uint8_t)0;
-        }
-        #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t b = b0 + (uint32_t)sub + 16u * (uint32_t)k;
-          if (b < len) dst[b] = v[k];
-        }
+// ---- final layout: alignments of read r at alns[read_aln_off[r]..], op streams back to back in the same order (gx
+// ops, then tx ops of an exonic alignment) ----
+// A read's alignments follow one another in its op stream, so a read is a serial chain: a few dependent loads and
+// ~200 bytes of copying per alignment, about 4 us each.  With one 16-lane group per read the launch lasted as long
+// as its most multi-mapped read (58 alignments on the chr21-sized text: 0.25 ms of a 0.29 ms launch; 1 300 on the
+// 2.2 G-symbol text, whose repeat families are larger: 1.9 ms).  Reads beyond COMPACT_HEAVY_N alignments therefore go
+// through two more kernels: a scan of their op lengths (one workgroup per read), then the copies, four alignments per
+// group, all groups of the grid at once.
+constexpr uint32_t COMPACT_HEAVY_N = 8, COMPACT_CHUNK = 4;
+
+// A candidate record as the 16 lanes of a group hold it: lane j its dwords j and 16 + j (Cand and thm_aln are 28 dwords
+// each; two coalesced loads, two coalesced stores, and the record never occupies 28 registers of every lane).
+struct CandRegs {
+  uint32_t lo, hi;
+};
+static_assert(sizeof(Cand) == 112 && sizeof(thm_aln) == 112, "compact_emit permutes the dwords of these layouts");
+static_assert(offsetof(Cand, ops_off) == 48 && offsetof(Cand, tx_ops_off) == 56 && offsetof(Cand, score) == 64 &&
+                  offsetof(Cand, ops_len) == 80 && offsetof(Cand, tx_ops_len) == 84 && offsetof(Cand, strand) == 108 &&
+                  offsetof(thm_aln, ops_off) == 24 && offsetof(thm_aln, tx_ops_off) == 56 && offsetof(thm_aln, xlen) == 80 &&
+                  offsetof(thm_aln, ops_len) == 84 && offsetof(thm_aln, tx_ops_len) == 104 && offsetof(thm_aln, strand) == 108,
+              "compact_emit permutes the dwords of these layouts");
+
+__device__ __forceinline__ CandRegs cand_load(const Cand* c, int sub) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(c);
+  CandRegs r;
+  r.lo = w[sub];
+  r.hi = sub < 12 ? w[16 + sub] : 0u;
+  return r;
+}
+
+// alignment `ai` of the batch: op streams to ops[o..], record to alns[ai]; returns the op bytes written
+__device__ __forceinline__ uint32_t compact_emit(const CompactParams& p, const CandRegs c, uint64_t ai, uint64_t o, uint32_t xlen, bool primary, int sub) {
+  const uint64_t ops_off = (uint64_t)__shfl(c.lo, 12, 16) | ((uint64_t)__shfl(c.lo, 13, 16) << 32);
+  const uint64_t tx_ops_off = (uint64_t)__shfl(c.lo, 14, 16) | ((uint64_t)__shfl(c.lo, 15, 16) << 32);
+  const uint32_t ops_len = __shfl(c.hi, 4, 16), tx_ops_len = __shfl(c.hi, 5, 16), flags = __shfl(c.hi, 11, 16);
+  if (ai >= p.alns_cap || o + ops_len + tx_ops_len > p.ops_cap) return ops_len + tx_ops_len;  // never without a fault; keeps every store in bounds
+  // 64 bytes per step of the 16 lanes, the four loads of a lane in flight together (a byte at a time would be one
+  // memory round trip per 16 bytes)
+  auto copy_ops = [&](const uint8_t* src, uint8_t* dst, uint32_t len) {
+    #pragma unroll 1
+    for (uint32_t b0 = 0; b0 < len; b0 += 64) {
+      uint8_t v[4];
+      #pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t b = b0 + (uint32_t)sub + 16u * (uint32_t)k;
+        v[k] = (b < len) ? src[b] : (uint8_t)0;
       }
-    };
-    copy_ops(p.cand_ops + cd.ops_off, p.ops + o, cd.ops_len);
-    const uint64_t go = o;
-    o += cd.ops_len;
-    copy_ops(p.cand_ops + cd.tx_ops_off, p.ops + o, cd.tx_ops_len);
-    const uint64_t to = o;
-    o += cd.tx_ops_len;
-    if (sub == 0) {
-      thm_aln a;
-      a.ystart = cd.ystart;
-      a.yend = cd.yend;
-      a.ylen = cd.ylen;
-      a.ops_off = go;
-      a.tx_ystart = cd.tx_ystart;
-      a.tx_yend = cd.tx_yend;
-      a.tx_ylen = cd.tx_ylen;
-      a.tx_ops_off = (cd.aln_type == THM_ALN_EXONIC) ? to : 0;
-      a.score = cd.score;
-      a.ref_id = cd.ref_id;
-      a.xstart = cd.xstart;
-      a.xend = cd.xend;
-      a.xlen = xlen;
-      a.ops_len = cd.ops_len;
-      a.tx_or_gene_idx = cd.tx_or_gene_idx;
-      a.tx_score = cd.tx_score;
-      a.tx_xstart = cd.tx_xstart;
-      a.tx_xend = cd.tx_xend;
-      a.tx_ops_len = cd.tx_ops_len;
-      a.strand = cd.strand;
-      a.primary = (t == 0) ? 1 : 0;  // src/aligner.rs:185-187
-      a.aln_type = cd.aln_type;
-      a.pad_ = 0;
-      p.alns[a0 + t] = a;
+      #pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t b = b0 + (uint32_t)sub + 16u * (uint32_t)k;
+        if (b < len) dst[b] = v[k];
+      }
+    }
+  };
+  copy_ops(p.cand_ops + ops_off, p.ops + o, ops_len);
+  const uint64_t go = o, to = o + ops_len;
+  copy_ops(p.cand_ops + tx_ops_off, p.ops + to, tx_ops_len);
+  // the record: thm_aln dword i comes from Cand dword src(i), or is one of ops_off / tx_ops_off / xlen / the flag bytes
+  //   i        0  1  2  3  4  5  6  7  8  9 10 11 12 13 14 15 | 16 17 18 19 20 21 22 23 24 25 26 27
+  //   src(i)   0  1  2  3  4  5  go go 6  7  8  9 10 11 to to | 16 17 18 19 xl 20 22 23 24 25 21 fl
+  const int src_lo = (int)((0x00BA987600543210ull >> (4 * sub)) & 15u);
+  const int src_hi = (int)((0x0000B59876403210ull >> (4 * sub)) & 15u);  // (lane of c.hi = Cand dword - 16)
+  uint32_t w0 = __shfl(c.lo, src_lo, 16), w1 = __shfl(c.hi, src_hi, 16);
+  const uint64_t txo = ((flags >> 8) & 0xFFu) == THM_ALN_EXONIC ? to : 0ull;
+  if (sub == 6) w0 = (uint32_t)go;
+  if (sub == 7) w0 = (uint32_t)(go >> 32);
+  if (sub == 14) w0 = (uint32_t)txo;
+  if (sub == 15) w0 = (uint32_t)(txo >> 32);
+  if (sub == 4) w1 = xlen;
+  // Cand: strand, aln_type, primary, pad -> thm_aln: strand, primary (src/aligner.rs:185-187), aln_type, pad
+  if (sub == 11) w1 = (flags & 0xFFu) | ((primary ? 1u : 0u) << 8) | (((flags >> 8) & 0xFFu) << 16);
+  uint32_t* out = reinterpret_cast<uint32_t*>(p.alns + ai);
+  out[sub] = w0;
+  if (sub < 12) out[16 + sub] = w1;
+  return ops_len + tx_ops_len;
+}
+
+// a faulted attempt (pool overflow) is replayed by the host with larger pools: its counts and offsets are not to be trusted
+__device__ __forceinline__ bool compact_faulted(const CompactParams& p) { return p.fault[0] != 0 || (p.fault[1] & FAULT_OPS_POOL) != 0; }
+
+template <int K>
+__global__ __launch_bounds__(256) void compact_kernel(CompactParams p) {
+  // 16 lanes per read (four reads per wavefront), the groups striding over the reads: one workgroup per 16 reads
+  // (31 250 of them for a batch of 500 000, their waves alive for 2.5 us each) kept a seventh of the wave slots
+  // occupied (SQ_WAVE_CYCLES / duration, profiles/r03/sq_counters_bench.json).  A read is a chain of dependent
+  // loads (count -> offsets -> order -> candidate -> op bytes), so a group works on K reads at once, each link of
+  // the K chains in flight together.
+  const int sub = (int)(threadIdx.x & 15u);
+  if (compact_faulted(p)) return;
+  const uint64_t n_groups = (uint64_t)gridDim.x * 16, g = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  for (uint64_t rb = g; rb < p.n_reads; rb += (uint64_t)K * n_groups) {
+    uint32_t n[K], xlen[K], l0[K];
+    uint64_t cand0[K], a0[K], o[K];
+    #pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint64_t r = rb + (uint64_t)k * n_groups;
+      n[k] = r < p.n_reads ? p.read_n_alns[r] : 0u;
+    }
+    #pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint64_t r = rb + (uint64_t)k * n_groups;
+      if (n[k] > COMPACT_HEAVY_N) {
+        if (sub == 0) {
+          const unsigned long long h = atomicAdd(&p.heavy_cnt[0], 1ull);
+          if (h < p.heavy_cap) p.heavy_list[h] = r;
+        }
+        n[k] = 0;
+      }
+      if (n[k]) {
+        cand0[k] = p.read_cand_off[r];
+        a0[k] = p.read_aln_off[r];
+        o[k] = p.read_ops_off[r];
+        xlen[k] = (uint32_t)(p.read_offsets[r + 1] - p.read_offsets[r]);
+      }
+    }
+    #pragma unroll
+    for (int k = 0; k < K; k++)
+      if (n[k]) l0[k] = p.order[2 * cand0[k]];
+    CandRegs cd[K];
+    #pragma unroll
+    for (int k = 0; k < K; k++)
+      if (n[k]) cd[k] = cand_load(p.cands + cand0[k] + l0[k], sub);
+    #pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (!n[k]) continue;
+      uint64_t ok = o[k] + compact_emit(p, cd[k], a0[k], o[k], xlen[k], true, sub);
+      const uint32_t* la = p.order + 2 * cand0[k];
+      for (uint32_t t = 1; t < n[k]; t++)  // (one read in forty has a second alignment)
+        ok += compact_emit(p, cand_load(p.cands + cand0[k] + la[t], sub), a0[k] + t, ok, xlen[k], false, sub);
+    }
+  }
+}
+
+// heavy reads, step 1: rel[a0 + t] = op bytes of the read's alignments before t; one descriptor per COMPACT_CHUNK alignments
+__global__ __launch_bounds__(256) void compact_heavy_scan_kernel(CompactParams p) {
+  __shared__ uint32_t wave_sum[4];
+  __shared__ unsigned long long desc_base;
+  if (compact_faulted(p)) return;
+  const uint64_t H = min((unsigned long long)p.heavy_cap, p.heavy_cnt[0]);
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (uint64_t h = blockIdx.x; h < H; h += gridDim.x) {
+    const uint64_t r = p.heavy_list[h];
+    const uint32_t n = p.read_n_alns[r];
+    const uint64_t cand0 = p.read_cand_off[r], a0 = p.read_aln_off[r];
+    const Cand* cands = p.cands + cand0;
+    const uint32_t* la = p.order + 2 * cand0;
+    uint32_t carry = 0;
+    for (uint32_t tile = 0; tile < n; tile += 256) {
+      const uint32_t t = tile + (uint32_t)tid;
+      uint32_t len = 0;
+      if (t < n) {
+        const Cand* cd = &cands[la[t]];
+        len = cd->ops_len + cd->tx_ops_len;
+      }
+      uint32_t inc = len;  // inclusive scan within the wave
+      #pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+      }
+      if (lane == 63) wave_sum[wv] = inc;
+      __syncthreads();
+      uint32_t before = carry, total = 0;
+      #pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (k < wv) before += wave_sum[k];
+        total += wave_sum[k];
+      }
+      if (t < n && a0 + t < p.alns_cap) p.rel[a0 + t] = before + inc - len;
+      carry += total;
+      __syncthreads();
+    }
+    const uint32_t nd = (n + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
+    if (tid == 0) desc_base = atomicAdd(&p.heavy_cnt[1], (unsigned long long)nd);
+    __syncthreads();
+    const unsigned long long base = desc_base;
+    for (uint32_t k = (uint32_t)tid; k < nd; k += 256)
+      if (base + k < p.heavy_cap) p.heavy_desc[base + k] = (r << 24) | (uint64_t)k;
+    __syncthreads();
+  }
+}
+
+// heavy reads, step 2: a 16-lane group per descriptor
+__global__ __launch_bounds__(256) void compact_heavy_copy_kernel(CompactParams p) {
+  const int sub = (int)(threadIdx.x & 15u);
+  if (compact_faulted(p)) return;
+  const uint64_t D = min((unsigned long long)p.heavy_cap, p.heavy_cnt[1]);
+  const uint64_t n_groups = (uint64_t)gridDim.x * 16;
+  for (uint64_t d = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4; d < D; d += n_groups) {
+    const uint64_t desc = p.heavy_desc[d], r = desc >> 24;
+    const uint32_t t0 = (uint32_t)(desc & 0xFFFFFFu) * COMPACT_CHUNK, n = p.read_n_alns[r];
+    const uint64_t cand0 = p.read_cand_off[r], a0 = p.read_aln_off[r], o0 = p.read_ops_off[r];
+    const Cand* cands = p.cands + cand0;
+    const uint32_t* la = p.order + 2 * cand0;
+    const uint32_t xlen = (uint32_t)(p.read_offsets[r + 1] - p.read_offsets[r]);
+    for (uint32_t t = t0; t < n && t < t0 + COMPACT_CHUNK; t++) {
+      if (a0 + t >= p.alns_cap) break;
+      (void)compact_emit(p, cand_load(&cands[la[t]], sub), a0 + t, o0 + p.rel[a0 + t], xlen, t == 0, sub);
     }
   }
 }
@@ -2005,9 +2132,28 @@ hipError_t launch_counters_reduce(const unsigned long long* wave_counters, uint3
 }
 
 hipError_t launch_compact(const CompactParams& p, hipStream_t s) {
-  const unsigned blocks = (unsigned)((p.n_reads + 15) / 16);
+  static const unsigned n_cu = [] {
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return (unsigned)cu;
+  }();
+  // 8 workgroups of 256 threads fill a CU's wave slots
+  const unsigned blocks = (unsigned)std::min<uint64_t>((p.n_reads + 15) / 16, (uint64_t)n_cu * 8);
   if (blocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(dev::compact_kernel, dim3(blocks), dim3(256), 0, s, p);
+  static const int k_reads = [] {
+    const char* e = getenv("THM_COMPACT_K");
+    const int v = e ? atoi(e) : 2;
+    return v == 1 || v == 2 || v == 4 ? v : 2;
+  }();
+  if (k_reads == 1)
+    hipLaunchKernelGGL(dev::compact_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+  else if (k_reads == 2)
+    hipLaunchKernelGGL(dev::compact_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(dev::compact_kernel<4>, dim3(blocks), dim3(256), 0, s, p);
+  // the reads left on the heavy list (counts on the device: both launches find them empty for most batches)
+  hipLaunchKernelGGL(dev::compact_heavy_scan_kernel, dim3(n_cu), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(dev::compact_heavy_copy_kernel, dim3(n_cu * 4), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 

@@ -446,6 +446,13 @@ struct CompactParams {
   uint8_t* ops;
   const int* fault;  // [0] seed stage, [1] extend stage: a faulted attempt is replayed by the host, nothing is compacted
   uint64_t alns_cap, ops_cap;  // entries in alns[], bytes in ops[]
+  // reads with many alignments (kernels_extend.hip, "final layout"): [0] reads listed, [1] descriptors written (zero
+  // when the launch starts); heavy_list / heavy_desc hold heavy_cap entries each; rel one word per alignment
+  unsigned long long* heavy_cnt;
+  uint64_t* heavy_list;
+  uint64_t* heavy_desc;
+  uint32_t* rel;
+  uint64_t heavy_cap;
 };
 hipError_t launch_compact(const CompactParams& p, hipStream_t s);
 // counters[k] += sum over rows of wave_counters[row][k]

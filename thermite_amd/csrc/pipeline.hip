@@ -478,6 +478,8 @@ int enqueue_run(thm_aligner* a) {
   if (a->cand_ops_cap < ops_min) a->cand_ops_cap = ops_min;
   HIPCHK(a, a->e_cands.ensure(a->cand_cap * sizeof(Cand)));
   HIPCHK(a, a->e_order.ensure(a->cand_cap * 2 * 4));
+  HIPCHK(a, a->e_heavy.ensure((a->cand_cap / 2 + 16) * 2 * 8));
+  HIPCHK(a, a->e_rel.ensure(a->cand_cap * 4));
   HIPCHK(a, a->e_ops.ensure(a->cand_ops_cap + 64));
   HIPCHK(a, a->e_nalns.ensure((n + 1) * 4));
   HIPCHK(a, a->e_nalns64.ensure((n + 1) * 8));
@@ -553,6 +555,12 @@ int enqueue_run(thm_aligner* a) {
   cp.fault = a->d_fault.as<int>();
   cp.alns_cap = a->cand_cap;
   cp.ops_cap = a->cand_ops_cap;
+  // (a heavy read has more than 8 alignments and a descriptor stands for 4 of them: cand_cap / 2 entries hold either list)
+  cp.heavy_cap = a->cand_cap / 2 + 16;
+  cp.heavy_cnt = a->d_cursors.as<unsigned long long>() + 2;  // zeroed with the cursors when the batch starts
+  cp.heavy_list = a->e_heavy.as<uint64_t>();
+  cp.heavy_desc = a->e_heavy.as<uint64_t>() + cp.heavy_cap;
+  cp.rel = a->e_rel.as<uint32_t>();
   HIPCHK(a, launch_compact(cp, s));
   HIPCHK(a, hipEventRecord(a->ev[4], s));
   return THM_OK;
