@@ -459,3 +459,89 @@ def test_inflate_bad_streams_are_errors(tmp_path):
     p.write_bytes(bytes(zs))
     with pytest.raises(capi.ThermiteError):
         capi.debug_gunzip(p)
+
+
+def _big_fastq(n, seed):
+    rng = np.random.default_rng(seed)
+    reads = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (n, 91))]
+    quals = rng.choice(np.frombuffer(b"FFFFFFFF:,#", np.uint8), (n, 91))
+    return b"".join(b"@A00123:45:HXX:1:1101:%d:%d 1:N:0:ACGT\n" % (1000 + i % 30000, 1000 + i // 7) + reads[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n"
+                    for i in range(n))
+
+
+@pytest.mark.parametrize("threads", [2, 5])
+def test_parallel_inflate_equals_zlib(tmp_path, monkeypatch, threads):
+    """the chunk-parallel decoder (several threads on one gzip file): decoding that starts in the middle of the stream,
+    markers for the unknown window, resolved in stream order -- on streams cut into many small chunks"""
+    import zlib
+    monkeypatch.setenv("THM_INFLATE_CHUNK_KB", "64")
+    fq = _big_fastq(30000, 21)
+    rng = np.random.default_rng(22)
+    noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()  # incompressible: stored blocks inside level-6 output
+    cases = {"fastq": fq, "mixed": fq[: 1 << 20] + noise + fq[1 << 20 :]}
+    for name, data in cases.items():
+        for level in (1, 6, 9):
+            p = tmp_path / ("%s_%d.gz" % (name, level))
+            p.write_bytes(gzip.compress(data, level))
+            assert os.path.getsize(p) > 4 * 65536
+            for chunk in (4096, 1 << 20):
+                assert capi.debug_gunzip(p, chunk, threads=threads) == data, (name, level, chunk)
+    # members back to back: one per 60 KB of input (what bgzip writes), a few large ones, an empty one in between
+    members = b"".join(gzip.compress(fq[s : s + 60000], 6) for s in range(0, len(fq), 60000))
+    p = tmp_path / "bgzf_like.gz"
+    p.write_bytes(members)
+    assert capi.debug_gunzip(p, 1 << 20, threads=threads) == fq
+    p = tmp_path / "members.gz"
+    p.write_bytes(gzip.compress(fq, 1) + gzip.compress(b"", 6) + gzip.compress(noise, 6) + gzip.compress(fq, 9))
+    assert capi.debug_gunzip(p, 1 << 16, threads=threads) == fq + noise + fq
+    # no dynamic block anywhere (level 0: stored blocks only): no chunk has a start, one segment takes it all
+    p = tmp_path / "stored.gz"
+    p.write_bytes(gzip.compress(fq[: 2 << 20], 0))
+    assert capi.debug_gunzip(p, 1 << 20, threads=threads) == fq[: 2 << 20]
+    # fixed-Huffman blocks only
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+    p = tmp_path / "fixed.gz"
+    p.write_bytes(co.compress(fq[: 1 << 20]) + co.flush())
+    assert capi.debug_gunzip(p, 1 << 20, threads=threads) == fq[: 1 << 20]
+
+
+def test_parallel_inflate_bad_streams_are_errors(tmp_path, monkeypatch):
+    import struct
+    monkeypatch.setenv("THM_INFLATE_CHUNK_KB", "64")
+    data = _big_fastq(30000, 23)
+    z = gzip.compress(data, 6)
+    assert len(z) > 6 * 65536
+    bad = {"cut_half": z[: len(z) // 2], "cut_tail": z[:-5], "cut_trailer": z[:-8],
+           "crc": z[:-8] + struct.pack("<I", struct.unpack("<I", z[-8:-4])[0] ^ 0x10) + z[-4:],
+           "isize": z[:-4] + struct.pack("<I", len(data) + 3),
+           "second_member_cut": z + z[: len(z) // 3]}
+    rng = np.random.default_rng(4)
+    for k in range(24):  # a flipped bit anywhere: some segment does not decode, or does not end on the next start, or the CRC differs
+        zb = bytearray(z)
+        at = int(rng.integers(10, len(z) - 8))
+        zb[at] ^= 1 << int(rng.integers(0, 8))
+        bad["flip%d" % k] = bytes(zb)
+    for name, b in bad.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(b)
+        for threads in (1, 4):
+            with pytest.raises(capi.ThermiteError) as e:
+                capi.debug_gunzip(p, 1 << 16, threads=threads)
+            assert e.value.code == capi.ERR_IO, (name, threads)
+
+
+def test_parallel_inflate_feeds_the_fastq_parsers(tmp_path, monkeypatch):
+    """the FASTQ reader over the chunk-parallel decoder (THM_INFLATE_THREADS) gives the records of the plain file"""
+    monkeypatch.setenv("THM_INFLATE_CHUNK_KB", "64")
+    monkeypatch.setenv("THM_INFLATE_THREADS", "3")
+    fq = _big_fastq(20000, 25)
+    plain = tmp_path / "r.fastq"
+    plain.write_bytes(fq)
+    gz = tmp_path / "r.fastq.gz"
+    gz.write_bytes(gzip.compress(fq, 6))
+    want = _collect(capi.FastqReader(plain), 3000)
+    got = _collect(capi.FastqReader(gz), 3000)
+    assert want == got and len(want[0]) == 20000
+    blocks = capi.FastqReader(gz).all_by_blocks(1700)
+    flat = capi.FastqReader(plain).all_by_blocks(1700)
+    assert all(np.array_equal(blocks[k], flat[k]) for k in blocks)

@@ -208,6 +208,9 @@ def lib():
     L.thm_fastq_next_batch.restype = i32
     L.thm_fastq_next_batch.argtypes = [vp, u64, vp]
     L.thm_fastq_close.argtypes = [vp]
+    if hasattr(L, "thm_debug_gunzip_mt"):
+        L.thm_debug_gunzip_mt.restype = i32
+        L.thm_debug_gunzip_mt.argtypes = [C.c_char_p, u64, u32, vp, u64, C.POINTER(u64)]
     if hasattr(L, "thm_debug_gunzip"):
         L.thm_debug_gunzip.restype = i32
         L.thm_debug_gunzip.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
@@ -609,12 +612,13 @@ class Comm:
         self.close()
 
 
-def debug_gunzip(path, chunk=1 << 20, cap=None):
-    """test hook: a gzip file through the library's own inflater, `chunk` bytes per call -> bytes"""
+def debug_gunzip(path, chunk=1 << 20, cap=None, threads=1):
+    """test hook: a gzip file through the library's own inflater, `chunk` bytes per call -> bytes
+    (threads > 1: the chunk-parallel decoder, for files of at least four chunks of THM_INFLATE_CHUNK_KB)"""
     cap = cap if cap is not None else 64 * os.path.getsize(path) + (1 << 20)
     out = np.empty(cap, np.uint8)
     n = C.c_uint64(0)
-    rc = lib().thm_debug_gunzip(os.fsencode(str(path)), chunk, out.ctypes.data, cap, C.byref(n))
+    rc = lib().thm_debug_gunzip_mt(os.fsencode(str(path)), chunk, threads, out.ctypes.data, cap, C.byref(n))
     if rc != 0:
         raise ThermiteError(rc, _last_error())
     return out[: n.value].tobytes()

@@ -9,8 +9,10 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "io_internal.h"
@@ -338,8 +340,12 @@ int32_t thm_fastq_open(const char* path, thm_fastq** out) {
   thm_fastq* r = new thm_fastq();
   r->path = path;
   if (gz) {
+    // worker threads of the chunk-parallel decoder (a file of some size): a quarter of the hardware threads, 2 to 8,
+    // unless THM_INFLATE_THREADS says otherwise (1: the serial decoder on the caller's thread)
+    unsigned n_threads = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 4));
+    if (const char* e = getenv("THM_INFLATE_THREADS")) n_threads = (unsigned)std::max(1, std::min(64, atoi(e)));
     r->z = new thm::GzInflater();
-    r->z->open(fd, r->path);
+    r->z->open(fd, r->path, n_threads);
   } else {
     r->fd = fd;
   }

@@ -17,9 +17,20 @@
 #include <unistd.h>
 #include <zlib.h>  // crc32() for the tail bytes and for CPUs without PCLMULQDQ
 
+#include <sys/mman.h>
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cerrno>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "io_internal.h"
 #include "thermite_internal.h"
@@ -142,7 +153,7 @@ inline uint32_t dist_entry(int sym, int len) {
 // Canonical Huffman decoding table from code lengths (0 = unused).  false: over-subscribed, or no room for the
 // sub-tables.  An incomplete code leaves invalid entries behind (reported when the stream walks into one).
 template <class MakeEntry>
-bool build_table(const uint8_t* lens, int n_sym, int table_bits, uint32_t* table, int max_entries, MakeEntry make) {
+bool build_table(const uint8_t* lens, int n_sym, int table_bits, uint32_t* table, int max_entries, MakeEntry make, bool* complete = nullptr) {
   int count[16] = {0};
   for (int i = 0; i < n_sym; i++) count[lens[i]]++;
   count[0] = 0;
@@ -151,6 +162,7 @@ bool build_table(const uint8_t* lens, int n_sym, int table_bits, uint32_t* table
     left = (left << 1) - count[l];
     if (left < 0) return false;
   }
+  if (complete) *complete = left == 0;
   uint32_t next[16];
   uint32_t code = 0;
   for (int l = 1; l <= 15; l++) {
@@ -241,7 +253,10 @@ inline uint64_t load64(const uint8_t* p) {
 struct GzInflater::Impl {
   int fd = -1;
   std::string path;
-  std::vector<uint8_t> in;  // compressed bytes [ipos, iend), then IN_PAD zero bytes once the file has ended
+  std::vector<uint8_t> inbuf;    // streaming input: compressed bytes [ipos, iend), then IN_PAD zero bytes once the file has ended
+  const uint8_t* ib = nullptr;  // the input: inbuf.data(), or a whole file in memory (zero bytes readable behind its end)
+  bool quiet = false;           // block search: failures are expected, no message is built
+  bool strict = false;          // block search: only complete Huffman codes pass
   size_t ipos = 0, iend = 0;
   bool in_eof = false;
   uint64_t bitbuf = 0;
@@ -264,11 +279,11 @@ struct GzInflater::Impl {
   void fill(size_t want) {
     while (iend - ipos < want && !in_eof) {
       if (ipos > 0) {
-        memmove(in.data(), in.data() + ipos, iend - ipos);
+        memmove(inbuf.data(), inbuf.data() + ipos, iend - ipos);
         iend -= ipos;
         ipos = 0;
       }
-      const long n = ::read(fd, in.data() + iend, IN_CAP - iend);
+      const long n = ::read(fd, inbuf.data() + iend, IN_CAP - iend);
       if (n < 0) {
         if (errno == EINTR) continue;
         err = "read error in " + path + ": " + strerror(errno);
@@ -278,7 +293,7 @@ struct GzInflater::Impl {
       } else {
         iend += (size_t)n;
       }
-      if (in_eof) memset(in.data() + iend, 0, IN_PAD);
+      if (in_eof) memset(inbuf.data() + iend, 0, IN_PAD);
     }
   }
   // the bit reader's position as a byte position (whole bytes still in the bit buffer are handed back)
@@ -294,10 +309,28 @@ struct GzInflater::Impl {
     fill(n);
     return iend - ipos >= n;
   }
-  bool fail(const std::string& what) {
+  bool fail(const char* what) {
+    if (quiet) {
+      if (err.empty()) err = "x";
+      return false;
+    }
     if (err.empty()) err = "gzip read error in " + path + ": " + what;
     return false;
   }
+  // a whole file in memory: decoding starts at any bit
+  void open_memory(const uint8_t* base, size_t size, const std::string& name) {
+    ib = base;
+    iend = size;
+    in_eof = true;
+    path = name;
+  }
+  void set_bit_position(uint64_t bit) {
+    ipos = (size_t)(bit >> 3);
+    const int skip = (int)(bit & 7);
+    bitbuf = (uint64_t)(ib[ipos++] >> skip);
+    bitcnt = 8 - skip;
+  }
+  uint64_t bit_position() const { return (uint64_t)ipos * 8 - (uint64_t)bitcnt; }
 
   bool member_header() {
     // between members: zero padding / nothing means the end
@@ -307,7 +340,7 @@ struct GzInflater::Impl {
       return true;
     }
     if (!bytes(10)) return fail("truncated stream");
-    const uint8_t* h = in.data() + ipos;
+    const uint8_t* h = ib + ipos;
     if (h[0] != 0x1f || h[1] != 0x8b) {
       if (n_members == 0) return fail("not a gzip stream");
       // bytes behind the last member that are not a member: zlib's gzread ignores them ("trailing garbage")
@@ -320,7 +353,7 @@ struct GzInflater::Impl {
     ipos += 10;
     if (flg & 4) {  // FEXTRA
       if (!bytes(2)) return fail("truncated stream");
-      const size_t xlen = in[ipos] | ((size_t)in[ipos + 1] << 8);
+      const size_t xlen = ib[ipos] | ((size_t)ib[ipos + 1] << 8);
       ipos += 2;
       if (!bytes(xlen)) return fail("truncated stream");
       ipos += xlen;
@@ -329,7 +362,7 @@ struct GzInflater::Impl {
       if (flg & f) {
         for (;;) {
           if (!bytes(1)) return fail("truncated stream");
-          if (in[ipos++] == 0) break;
+          if (ib[ipos++] == 0) break;
         }
       }
     if (flg & 2) {  // FHCRC
@@ -347,7 +380,7 @@ struct GzInflater::Impl {
   bool need_bits(int n) {
     while (bitcnt < n) {
       if (!bytes(1)) return fail("truncated stream");
-      bitbuf |= (uint64_t)in[ipos++] << bitcnt;
+      bitbuf |= (uint64_t)ib[ipos++] << bitcnt;
       bitcnt += 8;
     }
     return true;
@@ -366,7 +399,7 @@ struct GzInflater::Impl {
     if (type == 0) {
       align_to_byte();
       if (!bytes(4)) return fail("truncated stream");
-      const uint32_t len = in[ipos] | ((uint32_t)in[ipos + 1] << 8), nlen = in[ipos + 2] | ((uint32_t)in[ipos + 3] << 8);
+      const uint32_t len = ib[ipos] | ((uint32_t)ib[ipos + 1] << 8), nlen = ib[ipos + 2] | ((uint32_t)ib[ipos + 3] << 8);
       if ((len ^ 0xFFFFu) != nlen) return fail("invalid stored block lengths");
       ipos += 4;
       stored_left = len;
@@ -398,7 +431,8 @@ struct GzInflater::Impl {
       cl[order[i]] = (uint8_t)take(3);
     }
     uint32_t clt[128 + 8];
-    if (!build_table(cl, 19, 7, clt, 128, [](int s, int l) { return ((uint32_t)s << 16) | (uint32_t)l; }))
+    bool complete = false;
+    if (!build_table(cl, 19, 7, clt, 128, [](int s, int l) { return ((uint32_t)s << 16) | (uint32_t)l; }, &complete) || (strict && !complete))
       return fail("invalid code lengths set");
     uint8_t lens[286 + 30 + 138];
     int n = 0;
@@ -431,9 +465,12 @@ struct GzInflater::Impl {
       n += rep;
     }
     if (lens[256] == 0) return fail("invalid code -- missing end-of-block");
-    if (!build_table(lens, hlit, LIT_BITS, lit, MAX_LIT_ENTRIES, lit_entry)) return fail("invalid literal/lengths set");
+    if (!build_table(lens, hlit, LIT_BITS, lit, MAX_LIT_ENTRIES, lit_entry, &complete) || (strict && !complete)) return fail("invalid literal/lengths set");
     group_literals(lit, lit4);
-    if (!build_table(lens + hlit, hdist, DIST_BITS, dist, MAX_DIST_ENTRIES, dist_entry)) return fail("invalid distances set");
+    int n_dist = 0;
+    for (int i = 0; i < hdist; i++) n_dist += lens[hlit + i] != 0;
+    // (one distance code of one bit, or none at all, is a valid incomplete set)
+    if (!build_table(lens + hlit, hdist, DIST_BITS, dist, MAX_DIST_ENTRIES, dist_entry, &complete) || (strict && !complete && n_dist > 1)) return fail("invalid distances set");
     state = HUFFMAN;
     return true;
   }
@@ -441,15 +478,29 @@ struct GzInflater::Impl {
   // The hot loop.  Runs while `out` is at least OUT_SLACK bytes below `out_end`; returns with the state moved on at
   // the end of the block, or unchanged when the output is full.  `floor` is the lowest address a match may reach.
   static constexpr size_t OUT_SLACK = 320;
-  bool huffman(uint8_t*& out_io, uint8_t* out_end, const uint8_t* floor) {
-    uint8_t* out = out_io;
-    uint8_t* const out_stop = out_end - OUT_SLACK;
+  template <class T>
+  static inline void put4(T* out, uint32_t v) {  // four literals (the caller advances by as many as are meant)
+    if constexpr (sizeof(T) == 1) {
+      memcpy(out, &v, 4);
+    } else {  // bytes b3 b2 b1 b0 -> 00b3 00b2 00b1 00b0, one 8-byte store
+      uint64_t x = v;
+      x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+      x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+      memcpy(out, &x, 8);
+    }
+  }
+  // T = uint8_t: bytes.  T = uint16_t: symbols, for decoding that starts in the middle of a stream -- the 32 Ki
+  // entries before the output hold markers that stand for the unknown window, and are copied like bytes.
+  template <class T>
+  bool huffman(T*& out_io, T* out_end, const T* floor) {
+    T* out = out_io;
+    T* const out_stop = out_end - OUT_SLACK;
     uint64_t bb = bitbuf;
     int bc = bitcnt;
-    const uint8_t* ip = in.data() + ipos;
-    const uint8_t* ip_safe = in.data() + iend - (in_eof ? 0 : 32);  // past this: fetch more of the file first
+    const uint8_t* ip = ib + ipos;
+    const uint8_t* ip_safe = ib + iend - (in_eof ? 0 : 32);  // past this: fetch more of the file first
     // at the end of the file the zero padding lets the loop read on; `ip_limit` is how far a valid stream can get
-    const uint8_t* ip_limit = in.data() + iend + 8;
+    const uint8_t* ip_limit = ib + iend + 8;
     const uint32_t* const lt = lit;
     const uint64_t* const l4 = lit4;
     const uint32_t* const dt = dist;
@@ -464,19 +515,19 @@ struct GzInflater::Impl {
       if (ip > ip_safe) {
         if (!in_eof) {
           // hand the position back, fetch, and go on
-          ipos = (size_t)(ip - in.data());
+          ipos = (size_t)(ip - ib);
           fill(IN_CAP / 2);
           if (!err.empty()) {
             ok = false;
             break;
           }
-          ip = in.data() + ipos;
-          ip_safe = in.data() + iend - (in_eof ? 0 : 32);
-          ip_limit = in.data() + iend + 8;
+          ip = ib + ipos;
+          ip_safe = ib + iend - (in_eof ? 0 : 32);
+          ip_limit = ib + iend + 8;
           continue;
         }
         // the bits taken so far must all have come out of the file (ip runs up to 8 bytes ahead of them)
-        if (ip > ip_limit || (int64_t)(ip - in.data()) * 8 - bc > (int64_t)iend * 8) {
+        if (ip > ip_limit || (int64_t)(ip - ib) * 8 - bc > (int64_t)iend * 8) {
           ok = fail("truncated stream");
           break;
         }
@@ -485,8 +536,7 @@ struct GzInflater::Impl {
       uint64_t e4 = l4[bb & ((1u << LIT_BITS) - 1)];
       // up to three table entries of literals per refill (3 x 11 bits at most)
       auto put_literals = [&] {
-        const uint32_t v = (uint32_t)(e4 >> 32);
-        memcpy(out, &v, 4);
+        put4(out, (uint32_t)(e4 >> 32));
         out += (e4 >> 8) & 7;
         bb >>= (e4 & 0xFF);
         bc -= (int)(e4 & 0xFF);
@@ -497,8 +547,7 @@ struct GzInflater::Impl {
         if (e4 & E_LIT) {
           put_literals();
           if (e4 & E_LIT) {
-            const uint32_t v = (uint32_t)(e4 >> 32);
-            memcpy(out, &v, 4);
+            put4(out, (uint32_t)(e4 >> 32));
             out += (e4 >> 8) & 7;
             bb >>= (e4 & 0xFF);
             bc -= (int)(e4 & 0xFF);
@@ -516,7 +565,7 @@ struct GzInflater::Impl {
         if ((e >> 16) != 0) {  // sub-table (the end-of-block entry has payload 0)
           e = lt[(e >> 16) + ((bb >> LIT_BITS) & ((1u << (e & 0xFF)) - 1))];
           if (e & E_LIT) {
-            *out++ = (uint8_t)(e >> 16);
+            *out++ = (T)((e >> 16) & 0xFF);
             bb >>= (e & 0xFF);
             bc -= (int)(e & 0xFF);
             continue;
@@ -559,21 +608,35 @@ struct GzInflater::Impl {
         ok = fail("invalid distance too far back");
         break;
       }
-      const uint8_t* src = out - distance;
-      uint8_t* const oe = out + len;
-      if (distance >= 16) {
+      const T* src = out - distance;
+      T* const oe = out + len;
+      constexpr uint32_t E16 = 16 / sizeof(T), E8 = 8 / sizeof(T);  // elements per 16 / 8 bytes
+      if (distance >= E16) {
         do {
           memcpy(out, src, 16);
-          out += 16;
-          src += 16;
+          out += E16;
+          src += E16;
         } while (out < oe);
       } else if (distance == 1) {
-        memset(out, *src, len);
-      } else if (distance >= 8) {
+        const T v = *src;
+        if constexpr (sizeof(T) == 1) {
+          memset(out, v, len);
+        } else {
+          uint64_t x = v;
+          x |= x << 16;
+          x |= x << 32;
+          T* q = out;
+          do {  // (may overshoot like the other copies)
+            memcpy(q, &x, 8);
+            memcpy(q + 4, &x, 8);
+            q += 8;
+          } while (q < oe);
+        }
+      } else if (distance >= E8) {
         do {
           memcpy(out, src, 8);
-          out += 8;
-          src += 8;
+          out += E8;
+          src += E8;
         } while (out < oe);
       } else {
         do *out++ = *src++;
@@ -583,7 +646,7 @@ struct GzInflater::Impl {
     }
     bitbuf = bb;
     bitcnt = bc;
-    ipos = (size_t)(ip - in.data());
+    ipos = (size_t)(ip - ib);
     out_io = out;
     return ok;
   }
@@ -591,18 +654,14 @@ struct GzInflater::Impl {
 
 GzInflater::GzInflater() : p_(new Impl()) {}
 GzInflater::~GzInflater() {
+  delete par_;  // (joins its threads before the mapping goes)
   if (p_->fd >= 0) close(p_->fd);
   delete p_;
 }
-void GzInflater::open(int fd, const std::string& path) {
-  p_->fd = fd;
-  p_->path = path;
-  p_->in.resize(Impl::IN_CAP + Impl::IN_PAD);
-}
 const std::string& GzInflater::error() const { return p_->err; }
+long GzInflater::read(uint8_t* dst, size_t cap, size_t history) { return par_ ? par_read(dst, cap) : serial_read(*p_, dst, cap, history); }
 
-long GzInflater::read(uint8_t* dst, size_t cap, size_t history) {
-  Impl& s = *p_;
+long GzInflater::serial_read(Impl& s, uint8_t* dst, size_t cap, size_t history) {
   if (!s.err.empty()) return -1;
   if (cap < 2 * Impl::OUT_SLACK) {
     s.err = "internal: inflate buffer too small";
@@ -637,7 +696,7 @@ long GzInflater::read(uint8_t* dst, size_t cap, size_t history) {
           ok = s.fail("truncated stream");
           break;
         }
-        memcpy(out, s.in.data() + s.ipos, n);
+        memcpy(out, s.ib + s.ipos, n);
         out += n;
         s.ipos += n;
         s.stored_left -= (uint32_t)n;
@@ -659,7 +718,7 @@ long GzInflater::read(uint8_t* dst, size_t cap, size_t history) {
           break;
         }
         crc_upto(out);
-        const uint8_t* t = s.in.data() + s.ipos;
+        const uint8_t* t = s.ib + s.ipos;
         const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
         const uint32_t want_len = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
         if (want_crc != s.crc) {
@@ -690,11 +749,617 @@ long GzInflater::read(uint8_t* dst, size_t cap, size_t history) {
   return (long)(out - dst);
 }
 
+
+
+
+// ---- several threads on one gzip file ----
+// A DEFLATE stream can only be decoded from its start: a match may reach 32 KiB back, into bytes a decoder that
+// starts in the middle has not seen.  What such a decoder can do (the idea of pugz and rapidgzip, restated here from
+// their published descriptions) is decode into 16-bit SYMBOLS, with 32 Ki marker symbols standing for the unknown
+// window, and leave the markers to be replaced once the bytes before are known.  The file is cut into chunks of
+// compressed bytes; for each chunk
+//   find     the first bit at which a non-final dynamic-Huffman block starts: a header with complete codes, whose
+//            block decodes without error and is followed by another valid header (worker thread);
+//   decode   from there to the start found for the next chunk, into symbols; gzip member trailers and headers on
+//            the way are recorded (worker thread);
+//   resolve  symbols -> bytes with the last 32 KiB of the segment before, CRC-32 of the pieces (worker thread; only
+//            the 32 KiB that the NEXT segment waits for are resolved on the consumer's thread, in stream order).
+// The consumer hands the bytes out in order and checks every member's CRC-32 and ISIZE from the pieces
+// (crc32_combine).  A segment that does not end exactly on the next start, or does not decode, is not trusted:
+// from the end of the last good segment the rest of the file is inflated serially, window known, and a corrupt
+// stream is reported by that decoder.
+namespace {
+struct Pool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  bool stop = false;
+  explicit Pool(unsigned n) {
+    for (unsigned i = 0; i < n; i++)
+      th.emplace_back([this] {
+        for (;;) {
+          std::function<void()> f;
+          {
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return stop || !q.empty(); });
+            if (q.empty()) return;
+            f = std::move(q.front());
+            q.pop_front();
+          }
+          f();
+        }
+      });
+  }
+  void submit(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      q.push_back(std::move(f));
+    }
+    cv.notify_one();
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+constexpr size_t WINDOW = 32768;
+constexpr uint16_t MARKER = 32768;  // symbols >= MARKER: window byte (symbol - MARKER)
+}  // namespace
+
+struct GzInflater::Par {
+  struct MemberEnd {
+    size_t at;  // symbols of the segment before the member's end
+    uint32_t crc, isize;
+  };
+  struct Chunk {
+    uint64_t k = 0;
+    // find
+    bool find_done = false, found = false;
+    bool at_member = false;  // the start is a gzip member header (bgzip files: every block is a member of its own)
+    uint64_t start_bit = 0;
+    // decode (chunks with a start)
+    bool dispatched = false, dec_done = false, ok = false, at_end = false;
+    uint64_t stop_bit = 0, end_bit = 0;
+    std::vector<uint16_t> sym;  // WINDOW markers, then the segment's symbols
+    size_t n = 0;
+    std::vector<MemberEnd> members;
+    std::string err;
+    // resolve
+    bool res_started = false, res_done = false;
+    std::vector<uint8_t> window_in, bytes;
+    std::vector<uint32_t> piece_crc;
+  };
+  const uint8_t* base = nullptr;
+  size_t size = 0;
+  void* map = nullptr;
+  size_t map_len = 0;
+  std::string path;
+  size_t chunk_bytes = 0;
+  uint64_t n_chunks = 0;
+  unsigned lookahead = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<uint64_t, std::unique_ptr<Chunk>> chunks;
+  bool cancel = false;
+  uint64_t next_find = 1;   // next chunk to look for a start in
+  uint64_t head = 0;        // chunk whose segment the consumer hands out next
+  size_t head_off = 0;      // bytes of it already handed out
+  uint64_t to_dispatch = 0; // lowest chunk with a start whose decode is not yet running
+  uint64_t to_resolve = 0;  // next segment in stream order waiting for its window
+  std::vector<uint8_t> window;  // last 32 KiB before segment `to_resolve`
+  std::vector<std::vector<uint16_t>> free_sym;  // buffers of consumed segments, reused at their size
+  std::vector<std::vector<uint8_t>> free_bytes;
+  uint32_t crc = 0;
+  uint64_t member_out = 0;
+  bool finished = false;
+  // serial tail (after a segment that could not be trusted)
+  std::unique_ptr<Impl> tail;
+  std::vector<uint8_t> tail_buf;
+  size_t tail_hist = 0, tail_have = 0, tail_off = 0;
+  std::unique_ptr<Pool> pool;  // last member: destroyed first, joins the workers
+
+  ~Par() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      cancel = true;
+    }
+    pool.reset();
+    if (map) munmap(map, map_len);
+  }
+
+  Chunk* get(uint64_t k) {  // (mu held)
+    auto& c = chunks[k];
+    if (!c) {
+      c.reset(new Chunk());
+      c->k = k;
+    }
+    return c.get();
+  }
+
+  // ---- find ----
+  void find_task(Chunk* c) {
+    uint64_t found_bit = 0;
+    bool found = false, at_member = false;
+    {
+      std::unique_ptr<Impl> f(new Impl());
+      f->open_memory(base, size, path);
+      f->quiet = f->strict = true;
+      std::vector<uint16_t> scratch(WINDOW + (1u << 20) + 1024, 0);
+      const uint64_t lo = c->k * (uint64_t)chunk_bytes * 8, hi = std::min<uint64_t>((c->k + 1) * (uint64_t)chunk_bytes * 8, (uint64_t)size * 8);
+      for (uint64_t bit = lo; bit < hi && !found; bit++) {
+        const uint64_t w = load64(base + (bit >> 3)) >> (bit & 7);
+        if ((bit & 7) == 0 && (w & 0xE0FFFFFFu) == 0x00088B1Fu && (bit >> 3) + 18 < size) {
+          // a gzip member header?  it must parse, and its first block must decode
+          f->err.clear();
+          f->ipos = (size_t)(bit >> 3);
+          f->bitbuf = 0;
+          f->bitcnt = 0;
+          f->n_members = 1;
+          f->state = Impl::MEMBER_HEADER;
+          if (f->member_header() && f->state == Impl::BLOCK_HEADER && f->block_header()) {
+            bool good = true;
+            if (f->state == Impl::HUFFMAN) {
+              uint16_t* out = scratch.data() + WINDOW;
+              good = f->huffman<uint16_t>(out, scratch.data() + scratch.size(), scratch.data()) && f->err.empty();
+              if (good && f->state == Impl::BLOCK_HEADER) good = f->block_header();
+            }
+            if (good) {
+              found = at_member = true;
+              found_bit = bit;
+              break;
+            }
+          }
+        }
+        if ((w & 7) != 4) continue;  // BFINAL = 0, BTYPE = 2
+        if (((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
+        const int hclen = (int)((w >> 13) & 15) + 4;
+        const uint64_t w2 = load64(base + ((bit + 17) >> 3)) >> ((bit + 17) & 7);  // (57 bits: 19 lengths of 3)
+        uint32_t kraft = 0;
+        for (int i = 0; i < hclen; i++) {
+          const uint32_t l = (uint32_t)(w2 >> (3 * i)) & 7;
+          if (l) kraft += 128u >> l;
+        }
+        if (kraft != 128) continue;  // the code-length code must be complete
+        {
+          std::lock_guard<std::mutex> g(mu);
+          if (cancel) break;
+        }
+        f->err.clear();
+        f->set_bit_position(bit);
+        f->state = Impl::BLOCK_HEADER;
+        if (!f->block_header() || f->state != Impl::HUFFMAN) continue;
+        uint16_t* out = scratch.data() + WINDOW;
+        if (!f->huffman<uint16_t>(out, scratch.data() + scratch.size(), scratch.data()) || !f->err.empty()) continue;
+        if (f->state == Impl::BLOCK_HEADER) {  // the block ended: what follows must be a block header too
+          if (!f->block_header()) continue;
+        } else if (f->state != Impl::HUFFMAN) {
+          continue;
+        }  // (else: a million symbols without an error)
+        found = true;
+        found_bit = bit;
+      }
+    }
+    {
+      std::lock_guard<std::mutex> g(mu);
+      c->found = found;
+      c->at_member = at_member;
+      c->start_bit = found_bit;
+      c->find_done = true;
+    }
+    cv.notify_all();
+  }
+
+  // ---- decode ----
+  void decode_task(Chunk* c) {
+    std::unique_ptr<Impl> d(new Impl());
+    d->open_memory(base, size, path);
+    d->n_members = 1;
+    if (c->at_member) {
+      d->ipos = (size_t)(c->start_bit >> 3);
+      d->state = Impl::MEMBER_HEADER;
+    } else {
+      d->set_bit_position(c->start_bit);
+      d->state = Impl::BLOCK_HEADER;
+    }
+    std::vector<uint16_t>& sym = c->sym;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (!free_sym.empty()) {
+        sym.swap(free_sym.back());
+        free_sym.pop_back();
+      }
+      if (!free_bytes.empty()) {
+        c->bytes.swap(free_bytes.back());
+        free_bytes.pop_back();
+      }
+    }
+    // (a segment of FASTQ inflates to 3 - 6 times its compressed length)
+    {
+      const size_t want = WINDOW + std::max<size_t>((size_t)((c->stop_bit ? c->stop_bit - c->start_bit : (uint64_t)chunk_bytes * 8) / 8) * 5, 1u << 20);
+      if (sym.size() < want) sym.resize(want);
+    }
+    for (size_t i = 0; i < WINDOW; i++) sym[i] = (uint16_t)(MARKER + i);
+    size_t n = 0;
+    bool ok = true, at_end = false, reached = false;
+    auto room = [&](size_t want) {
+      if (sym.size() - (WINDOW + n) < want) sym.resize(sym.size() + sym.size() / 2 + want);
+    };
+    while (ok && !reached && !at_end) {
+      switch (d->state) {
+        case Impl::BLOCK_HEADER: {
+          const uint64_t bp = d->bit_position();
+          if (c->stop_bit && bp >= c->stop_bit) {
+            ok = bp == c->stop_bit;
+            reached = true;
+            break;
+          }
+          ok = d->block_header();
+          break;
+        }
+        case Impl::HUFFMAN: {
+          room(1u << 18);
+          uint16_t* out = sym.data() + WINDOW + n;
+          ok = d->huffman<uint16_t>(out, sym.data() + sym.size(), sym.data()) && d->err.empty();
+          n = (size_t)(out - (sym.data() + WINDOW));
+          break;
+        }
+        case Impl::STORED: {
+          const size_t len = d->stored_left;
+          if (d->iend - d->ipos < len) {
+            ok = d->fail("truncated stream");
+            break;
+          }
+          room(len + 1024);
+          uint16_t* out = sym.data() + WINDOW + n;
+          for (size_t i = 0; i < len; i++) out[i] = d->ib[d->ipos + i];
+          n += len;
+          d->ipos += len;
+          d->stored_left = 0;
+          d->state = d->last_block ? Impl::TRAILER : Impl::BLOCK_HEADER;
+          break;
+        }
+        case Impl::TRAILER: {
+          d->align_to_byte();
+          if (d->ipos + 8 > d->iend) {
+            ok = d->fail("truncated stream");
+            break;
+          }
+          const uint8_t* t = d->ib + d->ipos;
+          MemberEnd e;
+          e.at = n;
+          e.crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+          e.isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+          c->members.push_back(e);
+          d->ipos += 8;
+          d->state = Impl::MEMBER_HEADER;
+          break;
+        }
+        case Impl::MEMBER_HEADER:
+          if (c->stop_bit && (uint64_t)d->ipos * 8 >= c->stop_bit && n + c->members.size() > 0) {
+            ok = (uint64_t)d->ipos * 8 == c->stop_bit;
+            reached = true;
+            break;
+          }
+          ok = d->member_header();
+          break;
+        case Impl::END:
+          at_end = true;
+          break;
+      }
+      if (ok && (n & 0xFFFFF) < 0x800) {  // now and then
+        std::lock_guard<std::mutex> g(mu);
+        if (cancel) ok = false;
+      }
+    }
+    if (at_end && c->stop_bit) ok = false;  // the stream ended before the start the next segment was given
+    {
+      std::lock_guard<std::mutex> g(mu);
+      c->n = n;
+      c->ok = ok;
+      c->at_end = at_end;
+      c->end_bit = d->state == Impl::MEMBER_HEADER ? (uint64_t)d->ipos * 8 : d->bit_position();
+      c->err = d->err;
+      c->dec_done = true;
+    }
+    cv.notify_all();
+  }
+
+  static inline uint8_t resolve1(uint16_t v, const uint8_t* win) { return v < 256 ? (uint8_t)v : win[v & (WINDOW - 1)]; }
+
+  // ---- resolve ----
+  void resolve_task(Chunk* c) {
+    const uint16_t* sy = c->sym.data() + WINDOW;
+    // symbol -> byte through one table (literals map to themselves, markers to the window): a load per symbol, no branch
+    std::vector<uint8_t> lut(65536, 0);
+    for (int i = 0; i < 256; i++) lut[i] = (uint8_t)i;
+    memcpy(lut.data() + MARKER, c->window_in.data(), WINDOW);
+    if (c->bytes.size() < c->n + 64) c->bytes.resize(c->n + 64);
+    uint8_t* b = c->bytes.data();
+    const uint8_t* t = lut.data();
+    size_t i = 0;
+    for (; i + 8 <= c->n; i += 8) {
+      b[i] = t[sy[i]];
+      b[i + 1] = t[sy[i + 1]];
+      b[i + 2] = t[sy[i + 2]];
+      b[i + 3] = t[sy[i + 3]];
+      b[i + 4] = t[sy[i + 4]];
+      b[i + 5] = t[sy[i + 5]];
+      b[i + 6] = t[sy[i + 6]];
+      b[i + 7] = t[sy[i + 7]];
+    }
+    for (; i < c->n; i++) b[i] = t[sy[i]];
+    size_t p = 0;
+    for (const MemberEnd& e : c->members) {
+      c->piece_crc.push_back(crc32_fast(0, b + p, e.at - p));
+      p = e.at;
+    }
+    c->piece_crc.push_back(crc32_fast(0, b + p, c->n - p));
+    {
+      std::lock_guard<std::mutex> g(mu);
+      free_sym.emplace_back(std::move(c->sym));  // (kept at its size: the next segment does not touch fresh pages)
+      c->sym = std::vector<uint16_t>();
+    }
+    {
+      std::lock_guard<std::mutex> g(mu);
+      c->res_done = true;
+    }
+    cv.notify_all();
+  }
+
+  // mu held: start whatever can start.  false: the segment at `to_resolve` cannot be trusted
+  bool advance(std::unique_lock<std::mutex>& g) {
+    // finds, a bounded distance ahead of the consumer
+    while (next_find < n_chunks && next_find < head + lookahead) {
+      Chunk* c = get(next_find++);
+      pool->submit([this, c] { find_task(c); });
+    }
+    // decodes: a chunk with a start, once the next start behind it is known (or the file has no further chunk)
+    for (;;) {
+      if (to_dispatch >= n_chunks) break;
+      Chunk* c = get(to_dispatch);
+      uint64_t j = to_dispatch + 1;
+      bool known = true;
+      while (j < n_chunks) {
+        auto it = chunks.find(j);
+        if (it == chunks.end() || !it->second->find_done) {
+          // (stretches without a start -- stored blocks, one huge block -- are searched on, beyond the look-ahead)
+          if (it == chunks.end() && j == next_find) {
+            Chunk* f = get(next_find++);
+            pool->submit([this, f] { find_task(f); });
+          }
+          known = false;
+          break;
+        }
+        if (it->second->found) break;
+        j++;
+      }
+      if (!known) break;
+      c->stop_bit = j < n_chunks ? chunks[j]->start_bit : 0;
+      c->dispatched = true;
+      pool->submit([this, c] { decode_task(c); });
+      to_dispatch = j;
+    }
+    // resolves, in stream order: the window of the next segment comes out of this one
+    while (to_resolve < n_chunks) {
+      auto it = chunks.find(to_resolve);
+      if (it == chunks.end() || !it->second->dispatched || !it->second->dec_done) break;
+      Chunk* c = it->second.get();
+      if (!c->ok) return false;
+      c->window_in = window;
+      // the window behind this segment: its last 32 KiB (or the old window shifted by what it produced)
+      if (c->n >= WINDOW) {
+        const uint16_t* sy = c->sym.data() + WINDOW + c->n - WINDOW;
+        std::vector<uint8_t> w(WINDOW);
+        for (size_t i = 0; i < WINDOW; i++) w[i] = resolve1(sy[i], c->window_in.data());
+        window.swap(w);
+      } else {
+        std::vector<uint8_t> w(WINDOW);
+        memcpy(w.data(), c->window_in.data() + c->n, WINDOW - c->n);
+        const uint16_t* sy = c->sym.data() + WINDOW;
+        for (size_t i = 0; i < c->n; i++) w[WINDOW - c->n + i] = resolve1(sy[i], c->window_in.data());
+        window.swap(w);
+      }
+      c->res_started = true;
+      pool->submit([this, c] { resolve_task(c); });
+      // the next segment in stream order: the next chunk with a start
+      uint64_t j = to_resolve + 1;
+      while (j < n_chunks) {
+        auto jt = chunks.find(j);
+        if (jt != chunks.end() && jt->second->find_done && jt->second->found) break;
+        j++;  // (its find is done: this segment was dispatched with the start behind it known)
+      }
+      to_resolve = c->at_end ? n_chunks : j;
+    }
+    (void)g;
+    return true;
+  }
+};
+
+bool GzInflater::open_parallel(int fd, const std::string& path, unsigned n_threads) {
+  struct stat st;
+  // compressed bytes per chunk; THM_INFLATE_CHUNK_KB lets the tests cut small files into many chunks
+  size_t CHUNK = 2u << 20;
+  if (const char* e = getenv("THM_INFLATE_CHUNK_KB")) CHUNK = (size_t)std::max(16L, atol(e)) << 10;
+  if (n_threads < 2 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < 4 * CHUNK) return false;
+  const size_t size = (size_t)st.st_size, page = (size_t)sysconf(_SC_PAGESIZE);
+  // the file, and a page of zeros behind it: the decoders read a few bytes past the end of their input
+  const size_t map_len = (size + page - 1) / page * page + page;
+  void* m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (m == MAP_FAILED) return false;
+  if (mmap(m, size, PROT_READ, MAP_PRIVATE | MAP_FIXED, fd, 0) == MAP_FAILED) {
+    munmap(m, map_len);
+    return false;
+  }
+  (void)madvise(m, size, MADV_SEQUENTIAL);
+  std::unique_ptr<Par> par(new Par());
+  par->map = m;
+  par->map_len = map_len;
+  par->base = (const uint8_t*)m;
+  par->size = size;
+  par->path = path;
+  par->chunk_bytes = CHUNK;
+  par->n_chunks = (size + CHUNK - 1) / CHUNK;
+  par->lookahead = 3 * n_threads + 2;
+  par->window.assign(WINDOW, 0);
+  // the first member's header: the first segment starts at its first block
+  Impl h;
+  h.open_memory(par->base, size, path);
+  if (!h.member_header() || h.state != Impl::BLOCK_HEADER) return false;  // (the serial reader reports what is wrong)
+  par->pool.reset(new Pool(n_threads));
+  {
+    std::unique_lock<std::mutex> g(par->mu);
+    Par::Chunk* c0 = par->get(0);
+    c0->find_done = c0->found = true;
+    c0->start_bit = (uint64_t)h.ipos * 8;
+    par->advance(g);
+  }
+  par_ = par.release();
+  return true;
+}
+
+void GzInflater::open(int fd, const std::string& path, unsigned n_threads) {
+  p_->fd = fd;
+  p_->path = path;
+  if (open_parallel(fd, path, n_threads)) return;
+  p_->inbuf.resize(Impl::IN_CAP + Impl::IN_PAD);
+  p_->ib = p_->inbuf.data();
+}
+
+long GzInflater::par_read(uint8_t* dst, size_t cap) {
+  Par& P = *par_;
+  Impl& s = *p_;  // (only its error string is used here)
+  if (!s.err.empty()) return -1;
+  if (cap == 0) return 0;
+  for (;;) {
+    if (P.tail) {  // serial from here on
+      if (P.tail_off == P.tail_have) {
+        // keep the last 32 KiB in front of the buffer, inflate behind them
+        const size_t have = P.tail_hist + P.tail_have, keep = std::min(have, WINDOW);
+        memmove(P.tail_buf.data() + WINDOW - keep, P.tail_buf.data() + WINDOW + P.tail_have - keep, keep);
+        P.tail_hist = keep;
+        const long n = serial_read(*P.tail, P.tail_buf.data() + WINDOW, P.tail_buf.size() - WINDOW, P.tail_hist);
+        if (n < 0) {
+          s.err = P.tail->err;
+          return -1;
+        }
+        if (n == 0) return 0;
+        P.tail_have = (size_t)n;
+        P.tail_off = 0;
+        if (!P.tail->err.empty()) s.err = P.tail->err;  // (bytes first, the error with the next call)
+      }
+      const size_t k = std::min(cap, P.tail_have - P.tail_off);
+      memcpy(dst, P.tail_buf.data() + WINDOW + P.tail_off, k);
+      P.tail_off += k;
+      return (long)k;
+    }
+    if (P.finished) return 0;
+    std::unique_lock<std::mutex> g(P.mu);
+    bool trusted = P.advance(g);
+    Par::Chunk* c = nullptr;
+    if (trusted) {
+      auto it = P.chunks.find(P.head);
+      c = it == P.chunks.end() ? nullptr : it->second.get();
+      if (!c || !c->res_done) {
+        // wait for the head segment (or for the news that it cannot be trusted)
+        P.cv.wait(g);
+        continue;
+      }
+    }
+    if (!trusted) {
+      // Serial from the start of the segment at `to_resolve`: everything before it has been resolved and is handed out
+      // first (head catches up with to_resolve), then the tail decoder takes over with the window known.
+      if (P.head != P.to_resolve) {
+        auto it = P.chunks.find(P.head);
+        c = it == P.chunks.end() ? nullptr : it->second.get();
+        if (!c || !c->res_done) {
+          P.cv.wait(g);
+          continue;
+        }
+      } else {
+        Par::Chunk* bad = P.chunks[P.to_resolve].get();
+        const uint64_t from = bad->start_bit;
+        const bool from_member = bad->at_member || P.to_resolve == 0;
+        P.cancel = true;
+        g.unlock();
+        P.pool.reset();  // (joins: nothing refers to the chunks any more)
+        g.lock();
+        P.chunks.clear();
+        P.tail.reset(new Impl());
+        P.tail->open_memory(P.base, P.size, P.path);
+        P.tail->n_members = 1;
+        if (from_member) {
+          P.tail->ipos = P.to_resolve == 0 ? 0 : (size_t)(from >> 3);
+          P.tail->n_members = P.to_resolve == 0 ? 0 : 1;
+          P.tail->state = Impl::MEMBER_HEADER;
+        } else {
+          P.tail->set_bit_position(from);
+          P.tail->state = Impl::BLOCK_HEADER;
+        }
+        P.tail->crc = P.crc;
+        P.tail->member_out = P.member_out;
+        P.tail_buf.resize(WINDOW + (4u << 20));
+        memcpy(P.tail_buf.data(), P.window.data(), WINDOW);
+        P.tail_hist = WINDOW;
+        P.tail_have = P.tail_off = 0;
+        continue;
+      }
+    }
+    // hand out bytes of the head segment; at its end check the members that ended in it
+    if (P.head_off < c->n) {
+      const size_t k = std::min(cap, c->n - P.head_off);
+      g.unlock();
+      memcpy(dst, c->bytes.data() + P.head_off, k);
+      P.head_off += k;
+      return (long)k;
+    }
+    size_t p = 0, piece = 0;
+    for (const Par::MemberEnd& e : c->members) {
+      const size_t len = e.at - p;
+      P.crc = (uint32_t)crc32_combine(P.crc, c->piece_crc[piece++], (z_off_t)len);
+      P.member_out += len;
+      if (P.crc != e.crc) s.err = "gzip read error in " + P.path + ": incorrect data check";
+      else if ((uint32_t)P.member_out != e.isize) s.err = "gzip read error in " + P.path + ": incorrect length check";
+      if (!s.err.empty()) return -1;
+      P.crc = 0;
+      P.member_out = 0;
+      p = e.at;
+    }
+    P.crc = (uint32_t)crc32_combine(P.crc, c->piece_crc[piece], (z_off_t)(c->n - p));
+    P.member_out += c->n - p;
+    const bool at_end = c->at_end;
+    // the next segment: the next chunk with a start
+    uint64_t j = P.head + 1;
+    while (j < P.n_chunks) {
+      auto jt = P.chunks.find(j);
+      if (jt != P.chunks.end() && jt->second->found) break;
+      j++;
+    }
+    P.free_bytes.emplace_back(std::move(c->bytes));
+    for (uint64_t k = P.head; k < j; k++) P.chunks.erase(k);
+    P.head = j;
+    P.head_off = 0;
+    if (at_end || P.head >= P.n_chunks) {
+      // a stream that does not end in a member trailer is reported by its decode task (not ok -> serial tail)
+      P.finished = true;
+    }
+  }
+}
+
 }  // namespace thm
 
 // test hook: the whole gzip file through GzInflater in calls of `chunk` bytes (so that matches, stored blocks and
 // members straddle calls); *n_out bytes land in out[0, cap).  THM_ERR_IO with the inflater's message on a bad stream.
+extern "C" int32_t thm_debug_gunzip_mt(const char* path, uint64_t chunk, uint32_t n_threads, uint8_t* out, uint64_t cap, uint64_t* n_out);
 extern "C" int32_t thm_debug_gunzip(const char* path, uint64_t chunk, uint8_t* out, uint64_t cap, uint64_t* n_out) {
+  return thm_debug_gunzip_mt(path, chunk, 1, out, cap, n_out);
+}
+// ... with n_threads worker threads (the chunk-parallel decoder for files of four chunks or more)
+extern "C" int32_t thm_debug_gunzip_mt(const char* path, uint64_t chunk, uint32_t n_threads, uint8_t* out, uint64_t cap, uint64_t* n_out) {
   if (!path || !out || !n_out || chunk < 1024) return THM_ERR_INVALID_ARG;
   const int fd = open(path, O_RDONLY);
   if (fd < 0) {
@@ -702,7 +1367,7 @@ extern "C" int32_t thm_debug_gunzip(const char* path, uint64_t chunk, uint8_t* o
     return THM_ERR_IO;
   }
   thm::GzInflater z;
-  z.open(fd, path);
+  z.open(fd, path, n_threads);
   constexpr size_t W = 32768;
   std::vector<uint8_t> buf(W + chunk);
   size_t hist = 0;

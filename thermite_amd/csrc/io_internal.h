@@ -61,7 +61,9 @@ class GzInflater {
   ~GzInflater();
   GzInflater(const GzInflater&) = delete;
   GzInflater& operator=(const GzInflater&) = delete;
-  void open(int fd, const std::string& path);  // takes the descriptor over
+  // Takes the descriptor over.  n_threads > 1 and a regular file of some size: the file is mapped and inflated by
+  // that many worker threads (io_inflate.cpp, "several threads on one gzip file"); the calling thread only collects.
+  void open(int fd, const std::string& path, unsigned n_threads = 1);
   // Up to `cap` further bytes of the inflated stream into dst (cap >= 1024; the call stops a few hundred bytes short
   // of cap rather than in the middle of a match).  dst[-history, 0) must hold the `history` bytes that came before
   // (min(bytes so far, 32768) of them: matches reach back there).  0: end of the input; -1: error().
@@ -70,7 +72,12 @@ class GzInflater {
 
  private:
   struct Impl;
+  struct Par;
   Impl* p_;
+  Par* par_ = nullptr;
+  bool open_parallel(int fd, const std::string& path, unsigned n_threads);
+  long par_read(uint8_t* dst, size_t cap);
+  static long serial_read(Impl& s, uint8_t* dst, size_t cap, size_t history);
 };
 
 // thm_writer_format_batch without the final concatenation: the text of the batch is
