@@ -305,7 +305,7 @@ extern "C" int32_t thm_align_files_multi(thm_aligner* const* aligners, uint32_t 
       n_gz += is_gz[pi];
     }
     const unsigned ahead_files = std::max(1u, std::min(n_gz, std::max(2u, n_threads / 4)));
-    size_t ahead_bytes = (size_t)2048 << 20;  // all inflaters together; THM_INFLATE_AHEAD_MB overrides
+    size_t ahead_bytes = (size_t)768 << 20;  // all inflaters together; THM_INFLATE_AHEAD_MB overrides
     if (const char* e = getenv("THM_INFLATE_AHEAD_MB")) ahead_bytes = (size_t)std::max(1L, atol(e)) << 20;
     auto top_up = [&](uint32_t from) {  // the inflaters of the next `ahead_files` gzip files at or behind `from`
       unsigned running = 0;

@@ -809,6 +809,30 @@ struct Pool {
 };
 constexpr size_t WINDOW = 32768;
 constexpr uint16_t MARKER = 32768;  // symbols >= MARKER: window byte (symbol - MARKER)
+
+// Segment buffers are kept for reuse at their size, across segments and across files: a fresh 20 MB buffer costs
+// 5 000 page faults and their zero-filling before the decoder has written a symbol, which is most of the time of
+// a short file.  A bounded number of them stays with the process.
+template <class T>
+struct BufferCache {
+  std::mutex mu;
+  std::vector<std::vector<T>> free;
+  static constexpr size_t KEEP = 48;
+  void take(std::vector<T>& v) {
+    std::lock_guard<std::mutex> g(mu);
+    if (!free.empty()) {
+      v.swap(free.back());
+      free.pop_back();
+    }
+  }
+  void give(std::vector<T>&& v) {
+    if (v.capacity() == 0) return;
+    std::lock_guard<std::mutex> g(mu);
+    if (free.size() < KEEP) free.emplace_back(std::move(v));
+  }
+};
+BufferCache<uint16_t> g_sym_cache;
+BufferCache<uint8_t> g_byte_cache;
 }  // namespace
 
 struct GzInflater::Par {
@@ -852,8 +876,7 @@ struct GzInflater::Par {
   uint64_t to_dispatch = 0; // lowest chunk with a start whose decode is not yet running
   uint64_t to_resolve = 0;  // next segment in stream order waiting for its window
   std::vector<uint8_t> window;  // last 32 KiB before segment `to_resolve`
-  std::vector<std::vector<uint16_t>> free_sym;  // buffers of consumed segments, reused at their size
-  std::vector<std::vector<uint8_t>> free_bytes;
+  unsigned inflight = 0, max_inflight = 0;  // segments between the start of their decoding and the consumer
   uint32_t crc = 0;
   uint64_t member_out = 0;
   bool finished = false;
@@ -869,6 +892,10 @@ struct GzInflater::Par {
       cancel = true;
     }
     pool.reset();
+    for (auto& kv : chunks) {
+      g_sym_cache.give(std::move(kv.second->sym));
+      g_byte_cache.give(std::move(kv.second->bytes));
+    }
     if (map) munmap(map, map_len);
   }
 
@@ -967,17 +994,8 @@ struct GzInflater::Par {
       d->state = Impl::BLOCK_HEADER;
     }
     std::vector<uint16_t>& sym = c->sym;
-    {
-      std::lock_guard<std::mutex> g(mu);
-      if (!free_sym.empty()) {
-        sym.swap(free_sym.back());
-        free_sym.pop_back();
-      }
-      if (!free_bytes.empty()) {
-        c->bytes.swap(free_bytes.back());
-        free_bytes.pop_back();
-      }
-    }
+    g_sym_cache.take(sym);
+    g_byte_cache.take(c->bytes);
     // (a segment of FASTQ inflates to 3 - 6 times its compressed length)
     {
       const size_t want = WINDOW + std::max<size_t>((size_t)((c->stop_bit ? c->stop_bit - c->start_bit : (uint64_t)chunk_bytes * 8) / 8) * 5, 1u << 20);
@@ -1099,11 +1117,8 @@ struct GzInflater::Par {
       p = e.at;
     }
     c->piece_crc.push_back(crc32_fast(0, b + p, c->n - p));
-    {
-      std::lock_guard<std::mutex> g(mu);
-      free_sym.emplace_back(std::move(c->sym));  // (kept at its size: the next segment does not touch fresh pages)
-      c->sym = std::vector<uint16_t>();
-    }
+    g_sym_cache.give(std::move(c->sym));  // (kept at its size: the next segment does not touch fresh pages)
+    c->sym = std::vector<uint16_t>();
     {
       std::lock_guard<std::mutex> g(mu);
       c->res_done = true;
@@ -1120,7 +1135,7 @@ struct GzInflater::Par {
     }
     // decodes: a chunk with a start, once the next start behind it is known (or the file has no further chunk)
     for (;;) {
-      if (to_dispatch >= n_chunks) break;
+      if (to_dispatch >= n_chunks || inflight >= max_inflight) break;
       Chunk* c = get(to_dispatch);
       uint64_t j = to_dispatch + 1;
       bool known = true;
@@ -1141,6 +1156,7 @@ struct GzInflater::Par {
       if (!known) break;
       c->stop_bit = j < n_chunks ? chunks[j]->start_bit : 0;
       c->dispatched = true;
+      inflight++;
       pool->submit([this, c] { decode_task(c); });
       to_dispatch = j;
     }
@@ -1183,7 +1199,7 @@ struct GzInflater::Par {
 bool GzInflater::open_parallel(int fd, const std::string& path, unsigned n_threads) {
   struct stat st;
   // compressed bytes per chunk; THM_INFLATE_CHUNK_KB lets the tests cut small files into many chunks
-  size_t CHUNK = 2u << 20;
+  size_t CHUNK = 1u << 20;
   if (const char* e = getenv("THM_INFLATE_CHUNK_KB")) CHUNK = (size_t)std::max(16L, atol(e)) << 10;
   if (n_threads < 2 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < 4 * CHUNK) return false;
   const size_t size = (size_t)st.st_size, page = (size_t)sysconf(_SC_PAGESIZE);
@@ -1204,7 +1220,8 @@ bool GzInflater::open_parallel(int fd, const std::string& path, unsigned n_threa
   par->path = path;
   par->chunk_bytes = CHUNK;
   par->n_chunks = (size + CHUNK - 1) / CHUNK;
-  par->lookahead = 3 * n_threads + 2;
+  par->lookahead = 4 * n_threads + 4;  // starts are searched this many chunks ahead (a search holds no buffer)
+  par->max_inflight = n_threads + 2;   // segments being decoded, resolved or waiting for the consumer (they hold the buffers)
   par->window.assign(WINDOW, 0);
   // the first member's header: the first segment starts at its first block
   Impl h;
@@ -1339,7 +1356,8 @@ long GzInflater::par_read(uint8_t* dst, size_t cap) {
       if (jt != P.chunks.end() && jt->second->found) break;
       j++;
     }
-    P.free_bytes.emplace_back(std::move(c->bytes));
+    g_byte_cache.give(std::move(c->bytes));
+    P.inflight--;
     for (uint64_t k = P.head; k < j; k++) P.chunks.erase(k);
     P.head = j;
     P.head_off = 0;

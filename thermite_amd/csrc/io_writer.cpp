@@ -576,7 +576,7 @@ bool bgzf_compress(const char* p, size_t n, std::string& out) {
                                    (unsigned char)(bsize & 0xff), (unsigned char)(bsize >> 8)};
     out.append((const char*)hdr, 18);
     out.append((const char*)buf.data(), clen);
-    le32(out, (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(p + off), (uInt)len));
+    le32(out, thm::crc32_fast(0, (const uint8_t*)(p + off), len));  // (carry-less multiplication: six times zlib's crc32)
     le32(out, (uint32_t)len);
     if (n == 0) break;
   }
