@@ -125,3 +125,43 @@ def test_cpp_thermite_aligner_wrapper(data_dir, golden_dir, tmp_path):
     # align_read proper returns the same records without TX / GX / GN / RE (src/wrapper.rs:136-139)
     n_rec = len([ln for ln in out.stdout.split(b"\n") if ln and not ln.startswith(b"@")])
     assert ("stripped_records %d still_tagged 0" % n_rec).encode() in out.stderr
+
+
+def test_blank_tail_block_and_parallel_gzip(data_dir, tmp_path, monkeypatch):
+    """(a) blank lines at the end of the input that fall into a block of their own (batch_reads divides the record
+    count) hold no read: nothing is uploaded for them, the output is that of the file without them -- and blank
+    lines in the middle of the input are an error in both parsers alike; (b) the same records through a gzip file
+    cut into many chunks for the chunk-parallel decoder give the same bytes out"""
+    fa, gtf = data_dir + "/GRCh38-2020-A-chrM.fasta", data_dir + "/GRCh38-2020-A-chrM.gtf"
+    t = refdata.load_reference(fa, gtf)
+    n = 4000
+    bases, off, _ = synth.simulate_reads(t, n, 91, sub_rate=0.02, indel_rate=0.004, stream=12)
+    seqs = [bytes(bases[int(off[i]): int(off[i + 1])]) for i in range(n)]
+    quals = [b"F" * len(s) for s in seqs]
+    names = [("q%d" % i).encode() for i in range(n)]
+    body = b"".join(b"@" + names[i] + b"\n" + seqs[i] + b"\n+\n" + quals[i] + b"\n" for i in range(n))
+    res = orc.Index(t).align_batch(bases, off, capi.CI_OPTS, n_threads=8)
+    want = ow.sam_header(t) + ow.format_batch(t, names, seqs, quals, res, "sam")
+    a = capi.Aligner(capi.Index.from_files(fa, gtf), capi.CI_OPTS)
+    p = tmp_path / "tail.fastq"
+    p.write_bytes(body + b"\n\n\n")
+    out = tmp_path / "tail.sam"
+    st = capi.align_files(a, [p], out, capi.FMT_SAM, batch_reads=1000, n_threads=4)  # 4 full blocks, then the blank one
+    assert open(out, "rb").read() == want and st["n_reads"] == n
+    mid = tmp_path / "mid.fastq"
+    cut = body.index(b"@q2000\n")
+    mid.write_bytes(body[:cut] + b"\n\n" + body[cut:])
+    with pytest.raises(capi.ThermiteError) as e:
+        capi.align_files(a, [mid], tmp_path / "mid.sam", capi.FMT_SAM, batch_reads=1000, n_threads=4)
+    assert e.value.code == capi.ERR_FORMAT
+    monkeypatch.setenv("THM_INFLATE_CHUNK_KB", "32")
+    monkeypatch.setenv("THM_INFLATE_THREADS", "3")
+    gz = tmp_path / "reads.fastq.gz"
+    gz.write_bytes(gzip.compress(body, 6))
+    assert os.path.getsize(gz) > 4 * 32768
+    out = tmp_path / "gz.sam"
+    st = capi.align_files(a, [gz, p], out, capi.FMT_SAM, batch_reads=700, n_threads=4)
+    both = ow.sam_header(t) + ow.format_batch(t, names + names, seqs + seqs, quals + quals, orc.Index(t).align_batch(
+        np.concatenate([bases, bases]), np.concatenate([off, off[1:] + off[-1]]), capi.CI_OPTS, n_threads=8), "sam")
+    assert open(out, "rb").read() == both and st["n_reads"] == 2 * n
+    a.close()

@@ -45,6 +45,9 @@ for r in range(rounds):
     a = capi.Aligner(ix, opts)
     if rng.random() < 0.25:  # small pools: overflow -> grow -> replay (thm_batch_sync)
         a.debug_set_pool_caps(smem_cap=int(rng.integers(64, 2000)), cand_cap=int(rng.integers(16, 2000)), ops_cap=int(rng.integers(4096, 100000)))
+    # either extend path: the fused wave-per-read kernels (default) or the problem-parallel one
+    tpr = bool(rng.random() < 0.5)
+    a.debug_set_flags(tpr=tpr)
     g = a.align_batch(b2, o2)
     ref = oix.align_batch(b2, o2, opts, n_threads=16)
     assert ref.counters[15] == 0
@@ -80,5 +83,5 @@ for r in range(rounds):
     rm = oix.all_smems(b2, o2, k)
     assert np.array_equal(go, rm.offsets) and all(np.array_equal(gm[f], rm.mems[f]) for f in ("ref_idx", "query_idx", "len"))
     a.close()
-    print("round %d ok: L=%d k=%d pct=%.2f n=%d (longest %d) alns=%d mems=%d (%.0fs)" % (r, L, k, pct, len(o2) - 1, int(np.diff(o2.astype(np.int64)).max()), len(g.alns), len(gm), time.time() - t0), flush=True)
+    print("round %d ok [%s]: L=%d k=%d pct=%.2f n=%d (longest %d) alns=%d mems=%d (%.0fs)" % (r, "problem-parallel" if tpr else "fused", L, k, pct, len(o2) - 1, int(np.diff(o2.astype(np.int64)).max()), len(g.alns), len(gm), time.time() - t0), flush=True)
 print("fuzz ok")
