@@ -154,11 +154,11 @@ def test_blank_tail_block_and_parallel_gzip(data_dir, tmp_path, monkeypatch):
     with pytest.raises(capi.ThermiteError) as e:
         capi.align_files(a, [mid], tmp_path / "mid.sam", capi.FMT_SAM, batch_reads=1000, n_threads=4)
     assert e.value.code == capi.ERR_FORMAT
-    monkeypatch.setenv("THM_INFLATE_CHUNK_KB", "32")
+    monkeypatch.setenv("THM_INFLATE_CHUNK_KB", "16")
     monkeypatch.setenv("THM_INFLATE_THREADS", "3")
     gz = tmp_path / "reads.fastq.gz"
     gz.write_bytes(gzip.compress(body, 6))
-    assert os.path.getsize(gz) > 4 * 32768
+    assert os.path.getsize(gz) > 4 * 16384  # (enough chunks for the parallel decoder to take the file)
     out = tmp_path / "gz.sam"
     st = capi.align_files(a, [gz, p], out, capi.FMT_SAM, batch_reads=700, n_threads=4)
     both = ow.sam_header(t) + ow.format_batch(t, names + names, seqs + seqs, quals + quals, orc.Index(t).align_batch(

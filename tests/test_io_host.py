@@ -545,3 +545,37 @@ def test_parallel_inflate_feeds_the_fastq_parsers(tmp_path, monkeypatch):
     blocks = capi.FastqReader(gz).all_by_blocks(1700)
     flat = capi.FastqReader(plain).all_by_blocks(1700)
     assert all(np.array_equal(blocks[k], flat[k]) for k in blocks)
+
+
+def test_own_deflate_inflates_to_the_input(tmp_path):
+    """the BAM writer's deflate (csrc/io_deflate.cpp): every block inflates to its input with zlib and with the
+    library's own inflate; incompressible input becomes a stored block; skewed alphabets exercise the length limit
+    of the Huffman codes"""
+    import zlib
+    rng = np.random.default_rng(31)
+    fq = _big_fastq(400, 32)
+    p = np.r_[np.full(3, 0.3), 0.1 * (0.5 ** np.arange(1, 254))]
+    p[-1] += 1.0 - p.sum()  # a geometric tail: Huffman depths beyond 15 before the limit is applied
+    cases = {
+        "empty": b"", "one": b"A", "short": b"abcabcabcabc", "fastq": fq[:65280], "zeros": bytes(65280),
+        "noise": rng.integers(0, 256, 65280, dtype=np.uint8).tobytes(),
+        "skew": bytes(rng.choice(np.arange(256, dtype=np.uint8), 65280, p=p)),
+        "runs": b"".join(bytes([int(c)]) * int(n) for c, n in zip(rng.integers(65, 70, 400), rng.integers(1, 700, 400)))[:65280],
+        "far": (rng.integers(0, 256, 30000, dtype=np.uint8).tobytes() * 3)[:65280],  # matches at distance 30000
+        "two_symbols": bytes(rng.choice(np.frombuffer(b"AB", np.uint8), 5000)),
+    }
+    for k in range(12):  # BAM-like records: binary fields, packed bases, runs of equal qualities
+        n = int(rng.integers(1, 65281))
+        cases["mixed%d" % k] = bytes(np.where(rng.random(n) < 0.5, rng.integers(0, 256, n), 70).astype(np.uint8))
+    for name, data in cases.items():
+        z = capi.debug_deflate_block(data)
+        assert zlib.decompress(z, -15) == data, name
+        if name == "noise":
+            assert len(z) == len(data) + 5  # stored
+        if name in ("zeros", "fastq", "runs"):
+            assert len(z) < len(data) // 2, (name, len(z))
+        # ... and through the gzip reader of this library (header + block + trailer)
+        import struct
+        g = tmp_path / (name + ".gz")
+        g.write_bytes(bytes([0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 0xFF]) + z + struct.pack("<II", zlib.crc32(data), len(data)))
+        assert capi.debug_gunzip(g) == data, name

@@ -208,6 +208,9 @@ def lib():
     L.thm_fastq_next_batch.restype = i32
     L.thm_fastq_next_batch.argtypes = [vp, u64, vp]
     L.thm_fastq_close.argtypes = [vp]
+    if hasattr(L, "thm_debug_deflate_block"):
+        L.thm_debug_deflate_block.restype = i32
+        L.thm_debug_deflate_block.argtypes = [vp, u64, vp, u64, C.POINTER(u64)]
     if hasattr(L, "thm_debug_gunzip_mt"):
         L.thm_debug_gunzip_mt.restype = i32
         L.thm_debug_gunzip_mt.argtypes = [C.c_char_p, u64, u32, vp, u64, C.POINTER(u64)]
@@ -610,6 +613,17 @@ class Comm:
 
     def __del__(self):
         self.close()
+
+
+def debug_deflate_block(data):
+    """test hook: at most 65280 bytes through the BAM writer's own deflate -> one raw DEFLATE stream"""
+    src = np.frombuffer(bytes(data), np.uint8) if len(data) else np.zeros(1, np.uint8)
+    out = np.empty(len(data) + len(data) // 8 + 1024, np.uint8)
+    n = C.c_uint64(0)
+    rc = lib().thm_debug_deflate_block(src.ctypes.data, len(data), out.ctypes.data, len(out), C.byref(n))
+    if rc != 0:
+        raise ThermiteError(rc, _last_error())
+    return out[: n.value].tobytes()
 
 
 def debug_gunzip(path, chunk=1 << 20, cap=None, threads=1):

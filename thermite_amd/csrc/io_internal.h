@@ -80,6 +80,15 @@ class GzInflater {
   static long serial_read(Impl& s, uint8_t* dst, size_t cap, size_t history);
 };
 
+// DEFLATE for the BAM writer's BGZF blocks (io_deflate.cpp): one complete raw DEFLATE stream (a single final block)
+// for at most 65280 input bytes; out must hold deflate_block_bound(n) bytes; returns the bytes written
+struct DeflateScratch {
+  uint32_t tok[0xff00 + 8];
+  uint16_t head[1 << 13];
+};
+size_t deflate_block_bound(size_t n);
+size_t deflate_block(const uint8_t* in, size_t n, uint8_t* out, DeflateScratch& sc);
+
 // thm_writer_format_batch without the final concatenation: the text of the batch is
 // chunks[0] ++ chunks[1] ++ ... (one chunk per formatting thread, valid until the next call on `w`)
 int writer_format_chunks(thm_writer* w, const thm_read_batch* reads, const thm_batch_view* res,

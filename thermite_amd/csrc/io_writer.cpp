@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -537,38 +538,53 @@ bool format_range_bam(const Ctx& c, const std::vector<int32_t>& sq_of_name, uint
   return true;
 }
 
-// BGZF: a series of gzip members of at most 64 KiB, each with a BC extra field giving its size
+// BGZF: a series of gzip members of at most 64 KiB, each with a BC extra field giving its size.
+// Deflate: csrc/io_deflate.cpp unless THM_BAM_LEVEL=0..9 asks for zlib at that level (the reference's writer is
+// flate2 at level 6; parity is defined on the inflated stream, the compressed bytes depend on the implementation as it
+// is).  At level 6 sixteen threads deflate some 3 M records a second -- a third of what the stages before deliver --
+// and the records leave unsorted, for a sorter that rewrites them anyway.
 bool bgzf_compress(const char* p, size_t n, std::string& out) {
   constexpr size_t BLOCK = 0xff00;
-  std::vector<unsigned char> buf(compressBound(BLOCK) + 64);
+  static const int level = [] {
+    const char* e = getenv("THM_BAM_LEVEL");
+    const int v = e && *e ? atoi(e) : -1;
+    return v < 0 || v > 9 ? -1 : v;
+  }();
+  std::vector<unsigned char> buf(std::max<size_t>(compressBound(BLOCK) + 64, thm::deflate_block_bound(BLOCK)));
+  std::unique_ptr<thm::DeflateScratch> scratch;
   // one deflate state for all blocks of the call (deflateInit2 allocates and clears ~270 KB: per 64 KiB block that is
   // a tenth of the work), reset between the members
   z_stream zs;
   memset(&zs, 0, sizeof zs);
-  // Level 1 unless THM_BAM_LEVEL says otherwise: the records leave unsorted, for a sorter that rewrites them anyway,
-  // and at level 6 sixteen threads deflate some 3 M records a second -- a third of what the stages before deliver.
-  // (Parity is defined on the inflated stream: the compressed bytes depend on the deflate implementation as it is.)
-  static const int level = [] {
-    const char* e = getenv("THM_BAM_LEVEL");
-    const int v = e && *e ? atoi(e) : 1;
-    return v < 0 || v > 9 ? 1 : v;
-  }();
-  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  if (level >= 0) {
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  } else {
+    scratch.reset(new thm::DeflateScratch());
+  }
   bool ok = true;
   for (size_t off = 0; off < n || (n == 0 && off == 0); off += BLOCK) {
     const size_t len = std::min(BLOCK, n - off);
-    if (off && deflateReset(&zs) != Z_OK) {
-      ok = false;
-      break;
+    size_t clen;
+    if (level >= 0) {
+      if (off && deflateReset(&zs) != Z_OK) {
+        ok = false;
+        break;
+      }
+      zs.next_in = (Bytef*)(p + off);
+      zs.avail_in = (uInt)len;
+      zs.next_out = buf.data();
+      zs.avail_out = (uInt)buf.size();
+      const int rc = deflate(&zs, Z_FINISH);
+      clen = zs.total_out;
+      if (rc != Z_STREAM_END) {
+        ok = false;
+        break;
+      }
+    } else {
+      clen = thm::deflate_block((const uint8_t*)(p + off), len, buf.data(), *scratch);
     }
-    zs.next_in = (Bytef*)(p + off);
-    zs.avail_in = (uInt)len;
-    zs.next_out = buf.data();
-    zs.avail_out = (uInt)buf.size();
-    const int rc = deflate(&zs, Z_FINISH);
-    const size_t clen = zs.total_out;
     const size_t bsize = clen + 25;  // whole block size - 1
-    if (rc != Z_STREAM_END || bsize > 0xffff) {
+    if (bsize > 0xffff) {
       ok = false;
       break;
     }
@@ -580,7 +596,7 @@ bool bgzf_compress(const char* p, size_t n, std::string& out) {
     le32(out, (uint32_t)len);
     if (n == 0) break;
   }
-  deflateEnd(&zs);
+  if (level >= 0) deflateEnd(&zs);
   return ok;
 }
 
