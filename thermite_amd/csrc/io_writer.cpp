@@ -441,7 +441,8 @@ bool format_range_bam(const Ctx& c, const std::vector<int32_t>& sq_of_name, uint
                       std::string& err) {
   const thm_index* ix = c.ix;
   std::vector<uint32_t> cig;
-  std::string txz;
+  std::string txz, tags;
+  s.reserve(s.size() + (size_t)(r1 - r0) * 320);
   for (uint64_t r = r0; r < r1; r++) {
     const uint8_t* name = c.reads->names + c.reads->name_off[r];
     const size_t name_len = (size_t)(c.reads->name_off[r + 1] - c.reads->name_off[r]);
@@ -458,17 +459,25 @@ bool format_range_bam(const Ctx& c, const std::vector<int32_t>& sq_of_name, uint
     const uint64_t a0 = c.res->read_aln_off[r], a1 = c.res->read_aln_off[r + 1];
     const uint64_t multimap = a1 - a0;
     auto fixed = [&](int32_t ref_id, int32_t pos, uint32_t mapq, uint32_t bin, uint32_t n_cig, uint32_t flag) {
-      le32(s, (uint32_t)ref_id);
-      le32(s, (uint32_t)pos);
-      s.push_back((char)(qn + 1));
-      s.push_back((char)mapq);
-      le16(s, bin);
-      le16(s, n_cig);
-      le16(s, flag);
-      le32(s, (uint32_t)L);
-      le32(s, (uint32_t)-1);  // next refID
-      le32(s, (uint32_t)-1);  // next pos
-      le32(s, 0);             // tlen
+      // the 32 fixed bytes behind block_size in one append (little-endian host, like every other table of this library)
+      uint8_t b[32];
+      auto p32 = [&](int at, uint32_t v) { memcpy(b + at, &v, 4); };
+      auto p16 = [&](int at, uint32_t v) {
+        b[at] = (uint8_t)(v & 0xff);
+        b[at + 1] = (uint8_t)(v >> 8);
+      };
+      p32(0, (uint32_t)ref_id);
+      p32(4, (uint32_t)pos);
+      b[8] = (uint8_t)(qn + 1);
+      b[9] = (uint8_t)mapq;
+      p16(10, bin);
+      p16(12, n_cig);
+      p16(14, flag);
+      p32(16, (uint32_t)L);
+      p32(20, (uint32_t)-1);  // next refID
+      p32(24, (uint32_t)-1);  // next pos
+      p32(28, 0);             // tlen
+      s.append((const char*)b, 32);
       s.append((const char*)name, qn);
       s.push_back('\0');
     };
@@ -505,12 +514,17 @@ bool format_range_bam(const Ctx& c, const std::vector<int32_t>& sq_of_name, uint
       le32(s, 0);
       fixed(sq_of_name[ref.name_id], (int32_t)pos, multimapq(multimap), reg2bin(pos, pos + (int64_t)std::max<uint64_t>(ref_len, 1)),
             (uint32_t)cig.size(), (al.strand ? 0u : 16u) | (al.primary ? 0u : 256u));
-      for (uint32_t w : cig) le32(s, w);
+      s.append((const char*)cig.data(), 4 * cig.size());
       bam_seq_qual(s, seq, L, qual, QL, al.strand != 0);
-      bam_int_tag(s, "AS", al.score);
-      bam_int_tag(s, "NH", (int64_t)multimap);
-      bam_int_tag(s, "HI", (int64_t)(a - a0 + 1));
-      bam_int_tag(s, "nM", (int64_t)cnt.n_subst);
+      {  // the four integer tags through a small buffer (7 bytes each at most)
+        std::string& t4 = tags;
+        t4.clear();
+        bam_int_tag(t4, "AS", al.score);
+        bam_int_tag(t4, "NH", (int64_t)multimap);
+        bam_int_tag(t4, "HI", (int64_t)(a - a0 + 1));
+        bam_int_tag(t4, "nM", (int64_t)cnt.n_subst);
+        s += t4;
+      }
       if (al.aln_type == THM_ALN_EXONIC) {
         const uint32_t t = al.tx_or_gene_idx;
         if (t >= ix->txs.size() || al.tx_ops_off + al.tx_ops_len > c.res->n_op_bytes) {
