@@ -817,7 +817,7 @@ template <class T>
 struct BufferCache {
   std::mutex mu;
   std::vector<std::vector<T>> free;
-  static constexpr size_t KEEP = 48;
+  static constexpr size_t KEEP = 24;  // (two files with ten segments in flight each)
   void take(std::vector<T>& v) {
     std::lock_guard<std::mutex> g(mu);
     if (!free.empty()) {
