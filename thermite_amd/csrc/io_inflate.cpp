@@ -653,11 +653,6 @@ struct GzInflater::Impl {
 };
 
 GzInflater::GzInflater() : p_(new Impl()) {}
-GzInflater::~GzInflater() {
-  delete par_;  // (joins its threads before the mapping goes)
-  if (p_->fd >= 0) close(p_->fd);
-  delete p_;
-}
 const std::string& GzInflater::error() const { return p_->err; }
 long GzInflater::read(uint8_t* dst, size_t cap, size_t history) { return par_ ? par_read(dst, cap) : serial_read(*p_, dst, cap, history); }
 
@@ -1195,6 +1190,12 @@ struct GzInflater::Par {
     return true;
   }
 };
+
+GzInflater::~GzInflater() {
+  delete par_;  // (joins its threads, then unmaps the file; Par is complete here)
+  if (p_->fd >= 0) close(p_->fd);
+  delete p_;
+}
 
 bool GzInflater::open_parallel(int fd, const std::string& path, unsigned n_threads) {
   struct stat st;

@@ -484,7 +484,7 @@ __device__ int lift_markers(W& c, const IX& ix, const thm_tx& tx, const uint8_t*
       if (seen + cnt >= need) {
         const int rank = need - seen;  // rank within this chunk, >= 1
         const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-        const bool mine = ((m >> lane) & 1ull) && (__popcll(m & le) == rank);
+        const bool mine = ((m >> lane) & 1ull) && ((int)__popcll(m & le) == rank);
         const unsigned long long sel = __ballot(mine);
         kstar = k0 + __builtin_ctzll(sel) + 1;
       }

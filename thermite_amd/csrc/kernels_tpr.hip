@@ -73,86 +73,6 @@ struct TCoord<uint64_t> {
   typedef long long S;
 };
 
-__device__ __forceinline__ uint64_t ld8(const uint8_t* p) {
-  uint64_t v;
-  __builtin_memcpy(&v, p, 8);  // one global_load_dwordx2 (unaligned access is enabled for global memory)
-  return v;
-}
-struct U16 {
-  uint64_t lo, hi;
-};
-__device__ __forceinline__ U16 ld16(const uint8_t* p) {
-  U16 v;
-  __builtin_memcpy(&v, p, 16);  // one global_load_dwordx4
-  return v;
-}
-// leading positions t < n with a[t] == b[t]; touches nothing outside [a, a + n) and [b, b + n)
-__device__ __forceinline__ int match_fwd(const uint8_t* a, const uint8_t* b, int n) {
-  int t = 0;
-  while (t + 16 <= n) {
-    const U16 x = ld16(a + t), y = ld16(b + t);
-    const uint64_t d0 = x.lo ^ y.lo, d1 = x.hi ^ y.hi;
-    if (d0) return t + (int)(__builtin_ctzll(d0) >> 3);
-    if (d1) return t + 8 + (int)(__builtin_ctzll(d1) >> 3);
-    t += 16;
-  }
-  while (t + 8 <= n) {
-    const uint64_t d = ld8(a + t) ^ ld8(b + t);
-    if (d) return t + (int)(__builtin_ctzll(d) >> 3);
-    t += 8;
-  }
-  while (t < n && a[t] == b[t]) t++;
-  return t;
-}
-// positions t < n with a[-1 - t] == b[-1 - t], walking backwards; touches nothing outside [a - n, a) and [b - n, b)
-__device__ __forceinline__ int match_bwd(const uint8_t* a, const uint8_t* b, int n) {
-  int t = 0;
-  while (t + 16 <= n) {
-    const U16 x = ld16(a - 16 - t), y = ld16(b - 16 - t);
-    const uint64_t d0 = x.lo ^ y.lo, d1 = x.hi ^ y.hi;
-    if (d1) return t + (int)(__builtin_clzll(d1) >> 3);
-    if (d0) return t + 8 + (int)(__builtin_clzll(d0) >> 3);
-    t += 16;
-  }
-  while (t + 8 <= n) {
-    const uint64_t d = ld8(a - 8 - t) ^ ld8(b - 8 - t);
-    if (d) return t + (int)(__builtin_clzll(d) >> 3);
-    t += 8;
-  }
-  while (t < n && a[-1 - t] == b[-1 - t]) t++;
-  return t;
-}
-
-// a[0 .. n) == b[0 .. n), and (through `uniform`) whether every a[t] equals the byte c; touches nothing outside the ranges
-__device__ __forceinline__ bool equal_and_uniform(const uint8_t* a, const uint8_t* b, int n, uint8_t c, bool& uniform) {
-  const uint64_t splat = 0x0101010101010101ull * (uint64_t)c;
-  uint64_t diff = 0, nonu = 0;
-  int t = 0;
-  while (t + 16 <= n) {
-    const U16 x = ld16(a + t), y = ld16(b + t);
-    diff |= (x.lo ^ y.lo) | (x.hi ^ y.hi);
-    nonu |= (x.lo ^ splat) | (x.hi ^ splat);
-    if (diff) {
-      uniform = false;
-      return false;
-    }
-    t += 16;
-  }
-  while (t + 8 <= n) {
-    const uint64_t x = ld8(a + t), y = ld8(b + t);
-    diff |= x ^ y;
-    nonu |= x ^ splat;
-    t += 8;
-  }
-  while (t < n) {
-    diff |= (uint64_t)(a[t] ^ b[t]);
-    nonu |= (uint64_t)(a[t] ^ c);
-    t++;
-  }
-  uniform = nonu == 0;
-  return diff == 0;
-}
-
 // One SwgExtend::extend call as the control kernel sees it.  rec < 0: the result is known in closed form (ops in
 // walk order from the seed outwards: Subst if sp == 0, then Match).  rec >= 0: a DP record.
 struct Side {
@@ -163,46 +83,6 @@ struct Side {
 };
 
 // Classification of one extension.  x0 / y0: the first symbols as the extension walks them; dir = +1 (right) or -1.
-__device__ __forceinline__ Side side_classify(const uint8_t* x0, const uint8_t* y0, int dir, int xlen, long long ylen, int xd) {
-  Side s;
-  s.score = s.xend = s.yend = s.n = 0;
-  s.sp = -1;
-  s.rec = -1;
-  s.ub = 0;
-  s.known = true;
-  if (xlen == 0 || ylen <= 0) return s;  // src/swg.rs:39-55 (the clip is implied by xend)
-  const bool first_eq = x0[0] == y0[0];
-  if (xlen == 1 && !first_eq) return s;  // one base that mismatches: no cell of row 1 exceeds 0 (2 - j at best)
-  s.known = false;
-  s.ub = xlen;
-  if (first_eq) return s;
-  // The rest of x and of y as forward ranges: a left extension walks both backwards, so its symbols 1 .. n-1 are the
-  // n - 1 bytes BEFORE the first ones.
-  const int n1 = xlen - 1;
-  const uint8_t* xa = dir > 0 ? x0 + 1 : x0 - n1;
-  const uint8_t* ya = dir > 0 ? y0 + 1 : y0 - n1;
-  // swg_one_mismatch_shortcut: |x| >= 3, |y| >= |x|, x_drop >= 1, x[0] != y[0], x[1..] == y[1..|x|), x not one repeated base
-  if (xlen >= 3 && ylen >= (long long)xlen && xd >= 1) {
-    bool uniform;  // x[1..] all equal to x[0]: one repeated base
-    if (equal_and_uniform(xa, ya, n1, x0[0], uniform) && !uniform) {
-      s.known = true;
-      s.score = s.ub = xlen - 2;
-      s.xend = s.yend = s.n = xlen;
-      s.sp = 0;
-      return s;
-    }
-  }
-  // upper bound for a first pair that mismatches: |x| - 1 if x == y[1 .. |x| + 1) (a leading deletion), else max(|x| - 2, 0)
-  bool lead_del = false;
-  if (ylen >= (long long)xlen + 1) {
-    const uint8_t* xf = dir > 0 ? x0 : x0 - n1;
-    const uint8_t* yf = dir > 0 ? y0 + 1 : y0 - 1 - n1;
-    lead_del = match_fwd(xf, yf, xlen) == xlen;
-  }
-  s.ub = lead_del ? xlen - 1 : max(xlen - 2, 0);
-  return s;
-}
-
 template <class S>
 struct TPath {
   int score, xstart, xend, nops, nl, len;  // nl ops of the left extension, then `len` Match, then the right extension's
@@ -491,7 +371,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         op[j].l = mk_side(T.l, t_xl);
         if (!op[j].r.known) {
           const unsigned X = (unsigned)(t_xr + bw + 1), yl = min(T.r.A, X);
-          if (!o.gx.r.known && t_q + t_len == q + len && yl == min(hgr.A, X) && (unsigned)T.r.eq >= yl) {
+          if (!o.gx.r.known && (unsigned)(t_q + t_len) == (unsigned)(q + len) && yl == (unsigned)min(hgr.A, X) && (unsigned)T.r.eq >= yl) {
             al_r[j] = any_alias = true;
           } else {
             seq = ix.tx_seq + ix.exon_grid[T.ent].seq_off;
@@ -500,7 +380,7 @@ __global__ __launch_bounds__(256, TPR_CTL_MINW) void extend_ctl_kernel(ExtendPar
         }
         if (!op[j].l.known) {
           const unsigned X = (unsigned)(t_xl + bw + 1), yl = min(T.l.A, X);
-          if (!o.gx.l.known && t_q == q && yl == min(hgl.A, X) && (unsigned)T.l.eq >= yl) {
+          if (!o.gx.l.known && (unsigned)t_q == (unsigned)q && yl == (unsigned)min(hgl.A, X) && (unsigned)T.l.eq >= yl) {
             al_l[j] = any_alias = true;
           } else {
             if (!seq) seq = ix.tx_seq + ix.exon_grid[T.ent].seq_off;
