@@ -579,3 +579,25 @@ def test_own_deflate_inflates_to_the_input(tmp_path):
         g = tmp_path / (name + ".gz")
         g.write_bytes(bytes([0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 0xFF]) + z + struct.pack("<II", zlib.crc32(data), len(data)))
         assert capi.debug_gunzip(g) == data, name
+
+
+def test_inflate_refill_right_before_a_byte_aligned_field(tmp_path):
+    """the streaming input buffer is refilled when fewer than 32 compressed bytes are left; a stored block, a tiny
+    final block or the member trailer right behind that point make the decoder hand back the whole bytes it holds in
+    its bit buffer -- which must still be in the buffer (found by tools/stress_gzip.py: 'invalid stored block
+    lengths' on a valid file)"""
+    import zlib
+    rng = np.random.default_rng(41)
+    body = b"".join(bytes([int(c)]) * int(k) for c, k in zip(rng.integers(60, 70, 300), rng.integers(1, 900, 300)))
+    for tail in range(0, 24):
+        for flush in (zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, None):
+            co = zlib.compressobj(6, zlib.DEFLATED, 31)
+            z = co.compress(body)
+            if flush is not None:
+                z += co.flush(flush)
+            data = body + bytes(rng.integers(65, 91, tail).astype(np.uint8))
+            z += co.compress(data[len(body):]) + co.flush()
+            p = tmp_path / "t.gz"
+            p.write_bytes(z)
+            for chunk in (1024, 1 << 20):
+                assert capi.debug_gunzip(p, chunk) == data, (tail, flush, chunk)

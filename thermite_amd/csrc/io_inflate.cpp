@@ -278,10 +278,13 @@ struct GzInflater::Impl {
   // at least `want` compressed bytes behind ipos, unless the file ends first (then zero padding stands behind iend)
   void fill(size_t want) {
     while (iend - ipos < want && !in_eof) {
-      if (ipos > 0) {
-        memmove(inbuf.data(), inbuf.data() + ipos, iend - ipos);
-        iend -= ipos;
-        ipos = 0;
+      // (the 8 bytes before ipos stay: up to 7 whole bytes of them sit in the bit buffer and are handed back by
+      // align_to_byte when a stored block or a member trailer follows)
+      if (ipos > 8) {
+        const size_t shift = ipos - 8;
+        memmove(inbuf.data(), inbuf.data() + shift, iend - shift);
+        iend -= shift;
+        ipos = 8;
       }
       const long n = ::read(fd, inbuf.data() + iend, IN_CAP - iend);
       if (n < 0) {
