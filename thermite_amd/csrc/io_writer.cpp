@@ -105,6 +105,28 @@ bool put_cigar(std::string& s, const uint8_t* p, size_t n, OpCounts* cnt) {
     s.push_back(KIND[prev_k]);
   };
   for (size_t i = 0; i < n;) {
+    // fast path: a stretch of plain matches (most of every op stream), eight bytes at a time
+    if (p[i] == THM_OP_MATCH) {
+      size_t j = i;
+      uint64_t w8;
+      while (j + 8 <= n && (memcpy(&w8, p + j, 8), w8 == 0)) j += 8;
+      while (j < n && p[j] == THM_OP_MATCH) j++;
+      const uint64_t m = (uint64_t)(j - i);
+      if (cnt) {
+        cnt->n_match += m;
+        cnt->n_not_yclip += m;
+      }
+      if (prev_k == THM_OP_MATCH) {
+        run += m;
+      } else {
+        flush();
+        prev_k = THM_OP_MATCH;
+        prev_clip = 0;
+        run = m;
+      }
+      i = j;
+      continue;
+    }
     int k = p[i++];
     uint32_t clip = 0;
     if (k > THM_OP_YCLIP) return false;
@@ -129,6 +151,31 @@ bool put_cigar(std::string& s, const uint8_t* p, size_t n, OpCounts* cnt) {
     }
   }
   flush();
+  return true;
+}
+
+// the counts of put_cigar without the text (PAF prints only them)
+bool count_ops(const uint8_t* p, size_t n, OpCounts& cnt) {
+  for (size_t i = 0; i < n;) {
+    if (p[i] == THM_OP_MATCH) {
+      size_t j = i;
+      uint64_t w8;
+      while (j + 8 <= n && (memcpy(&w8, p + j, 8), w8 == 0)) j += 8;
+      while (j < n && p[j] == THM_OP_MATCH) j++;
+      cnt.n_match += (uint64_t)(j - i);
+      cnt.n_not_yclip += (uint64_t)(j - i);
+      i = j;
+      continue;
+    }
+    const int k = p[i++];
+    if (k > THM_OP_YCLIP) return false;
+    if (k >= THM_OP_XCLIP) {
+      if (i + 4 > n) return false;
+      i += 4;
+    }
+    cnt.n_subst += k == THM_OP_SUBST;
+    cnt.n_not_yclip += k != THM_OP_YCLIP;
+  }
   return true;
 }
 
@@ -182,8 +229,7 @@ bool format_range(const Ctx& c, uint64_t r0, uint64_t r1, std::string& s, std::s
       const uint8_t* ops = c.res->ops + al.ops_off;
       OpCounts cnt;
       if (c.format == THM_FMT_PAF) {
-        std::string dummy;
-        if (!put_cigar(dummy, ops, al.ops_len, &cnt)) {
+        if (!count_ops(ops, al.ops_len, cnt)) {
           err = "malformed op stream";
           return false;
         }
@@ -386,6 +432,28 @@ bool bam_cigar(std::vector<uint32_t>& out, const uint8_t* p, size_t n, OpCounts*
     if (prev_k == THM_OP_MATCH || prev_k == THM_OP_DEL || prev_k == THM_OP_YCLIP) ref_len += len;
   };
   for (size_t i = 0; i < n;) {
+    // fast path: a stretch of plain matches (most of every op stream), eight bytes at a time
+    if (p[i] == THM_OP_MATCH) {
+      size_t j = i;
+      uint64_t w8;
+      while (j + 8 <= n && (memcpy(&w8, p + j, 8), w8 == 0)) j += 8;
+      while (j < n && p[j] == THM_OP_MATCH) j++;
+      const uint64_t m = (uint64_t)(j - i);
+      if (cnt) {
+        cnt->n_match += m;
+        cnt->n_not_yclip += m;
+      }
+      if (prev_k == THM_OP_MATCH) {
+        run += m;
+      } else {
+        flush();
+        prev_k = THM_OP_MATCH;
+        prev_clip = 0;
+        run = m;
+      }
+      i = j;
+      continue;
+    }
     int k = p[i++];
     uint32_t clip = 0;
     if (k > THM_OP_YCLIP) return false;
