@@ -601,3 +601,21 @@ def test_inflate_refill_right_before_a_byte_aligned_field(tmp_path):
             p.write_bytes(z)
             for chunk in (1024, 1 << 20):
                 assert capi.debug_gunzip(p, chunk) == data, (tail, flush, chunk)
+
+
+def test_parallel_inflate_reader_closed_early(tmp_path, monkeypatch):
+    """a reader over the chunk-parallel decoder that is closed after the first batch joins its worker threads and
+    leaves nothing behind (finds, decodes and resolves of later chunks are still queued or running at that point)"""
+    import threading
+    monkeypatch.setenv("THM_INFLATE_CHUNK_KB", "16")
+    monkeypatch.setenv("THM_INFLATE_THREADS", "4")
+    gz = tmp_path / "r.fastq.gz"
+    gz.write_bytes(gzip.compress(_big_fastq(30000, 27), 6))
+    before = threading.active_count()
+    n_os = len(os.listdir("/proc/self/task"))
+    for _ in range(5):
+        r = capi.FastqReader(gz)
+        b = r.next_batch(100)
+        assert len(b["offsets"]) == 101
+        r.close()
+    assert len(os.listdir("/proc/self/task")) <= n_os and threading.active_count() == before
