@@ -215,7 +215,7 @@ void thm_aligner_free(thm_aligner* a) {
   if (a->stream3) (void)hipStreamSynchronize(a->stream3);
   if (a->stream4) (void)hipStreamSynchronize(a->stream4);
   DBuf* all[] = {&a->d_counters, &a->d_queue, &a->d_fault, &a->d_cursors, &a->b0, &a->b1, &a->b2, &a->b3, &a->b4,
-                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->e_wcnt, &a->t_memos, &a->t_recs, &a->t_dpops, &a->t_qlist, &a->t_act[0], &a->t_act[1], &a->t_ctl, &a->t_bail, &a->t_queue2, &a->t_trace, &a->t_ttrace, &a->t_hdr, &a->t_sums, &a->s_smems, &a->s_off, &a->s_cnt,
+                 &a->b5, &a->b6, &a->b7, &a->b8, &a->r_bases, &a->r_offsets, &a->r_san, &a->s_ms_end, &a->s_ms_lo, &a->s_ms_hi, &a->s_work_reads, &a->s_work_long, &a->s_work_cells, &a->s_work_counts, &a->s_fill_keys, &a->s_fill_perm, &a->s_fill_hist, &a->s_sel_scratch, &a->s_heavy, &a->s_slow, &a->s_team, &a->r_status, &a->e_slow, &a->e_recs, &a->e_wcnt, &a->t_memos, &a->t_recs, &a->t_dpops, &a->t_qlist, &a->t_act[0], &a->t_act[1], &a->t_ctl, &a->t_bail, &a->t_queue2, &a->t_trace, &a->t_ttrace, &a->t_hdr, &a->t_sums, &a->s_smems, &a->s_off, &a->s_cnt,
                  &a->s_hits, &a->s_cand_off, &a->scan_tmp, &a->e_cands, &a->e_heavy, &a->e_rel, &a->e_order, &a->e_ops, &a->e_nalns,
                  &a->e_nalns64, &a->e_opbytes, &a->e_aln_off, &a->e_ops_off, &a->e_trace, &a->o_alns, &a->o_ops, &a->o_mems};
   for (DBuf* b : all) b->release();

@@ -111,7 +111,7 @@ struct thm_aligner {
   bool uploaded = false;
   // seeds
   DBuf s_smems, s_off, s_cnt, s_hits, s_cand_off, scan_tmp, s_ms_end, s_ms_lo, s_ms_hi, s_work_reads, s_work_long, s_work_cells,
-      s_work_counts, s_sel_scratch, s_heavy, s_slow, s_team;
+      s_work_counts, s_sel_scratch, s_heavy, s_slow, s_team, s_fill_keys, s_fill_perm, s_fill_hist;
   uint64_t smem_cap = 0;
   // extension
   DBuf e_heavy, e_rel;  // compact stage: lists of reads with many alignments, op offsets of their alignments

@@ -405,22 +405,23 @@ __global__ __launch_bounds__(256) void seed_cells_kernel(SeedParamsT<C> p, const
   block_append(todo, (read << 16) | (unsigned long long)c, p.work_cells, &p.work_counts[1]);
 }
 
+// slot `tid` of the fill stage -> (read, position); false: nothing to probe there
 template <class C>
-__global__ __launch_bounds__(256) void seed_fill_kernel(SeedParamsT<C> p) {
-  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t ci = tid / PROBE_STRIDE;
-  if (ci >= p.work_counts[1]) return;
+__device__ __forceinline__ bool fill_item(const SeedParamsT<C>& p, uint64_t tid, uint64_t& read, int& pos, uint64_t& r0, int& L) {
   const int j = (int)(tid % PROBE_STRIDE);
-  if (j == 0) return;  // the cell's left end is a grid position
-  const unsigned long long w = p.work_cells[ci];
-  const uint64_t read = w >> 16;
+  if (j == 0) return false;  // the cell's left end is a grid position
+  const unsigned long long w = p.work_cells[tid / PROBE_STRIDE];
+  read = w >> 16;
   const int c = (int)(w & 0xffffu);
-  const uint64_t r0 = p.reads.offsets[read];
-  const int L = (int)(p.reads.offsets[read + 1] - r0);
+  r0 = p.reads.offsets[read];
+  L = (int)(p.reads.offsets[read + 1] - r0);
+  const int npos = L - (int)p.min_seed_len + 1;
+  pos = c * PROBE_STRIDE + j;
+  return pos < min(c * PROBE_STRIDE + PROBE_STRIDE, npos - 1);
+}
+template <class C>
+__device__ __forceinline__ void fill_probe(const SeedParamsT<C>& p, uint64_t read, int pos, uint64_t r0, int L) {
   const int k = (int)p.min_seed_len;
-  const int npos = L - k + 1;
-  const int pos = c * PROBE_STRIDE + j;
-  if (pos >= min(c * PROBE_STRIDE + PROBE_STRIDE, npos - 1)) return;
   int d = 0;
   C lo = 0, hi = 0;
   ms_search(p.ix, p.reads.bases + r0, L, pos, k, d, lo, hi);
@@ -428,6 +429,88 @@ __global__ __launch_bounds__(256) void seed_fill_kernel(SeedParamsT<C> p) {
   p.ms_end[item] = (uint16_t)((d >= k) ? pos + d : 0);
   p.ms_lo[item] = lo;
   p.ms_hi[item] = hi;
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void seed_fill_kernel(SeedParamsT<C> p) {
+  const uint64_t total = p.work_counts[1] * PROBE_STRIDE;
+  const uint64_t step = (uint64_t)gridDim.x * 256;  // (the worst-case grid covers every slot: one pass)
+  for (uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x; tid < total; tid += step) {
+    uint64_t read, r0;
+    int pos, L;
+    if (fill_item(p, tid, read, pos, r0, L)) fill_probe(p, read, pos, r0, L);
+  }
+}
+
+// ---- the probes in bucket order (fill_mode 2) ----
+template <class C>
+__global__ __launch_bounds__(256) void seed_fill_keys_kernel(SeedParamsT<C> p) {
+  const uint64_t total = p.work_counts[1] * PROBE_STRIDE;
+  const uint64_t step = (uint64_t)gridDim.x * 256;
+  for (uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x; tid < total; tid += step) {
+    uint64_t read, r0;
+    int pos, L;
+    uint16_t key = 0xFFFF;
+    if (fill_item(p, tid, read, pos, r0, L)) {
+      const uint64_t w0 = load8_global(p.reads.bases + r0 + pos);
+      uint32_t code = 0;
+      bool acgt = true;
+      for (int t = 0; t < FILL_KEY_BASES; t++) {
+        const int c = base_code((uint8_t)((w0 >> (8 * t)) & 0xff));
+        acgt = acgt && (c >= 0);
+        code = (code << 2) | (uint32_t)(c & 3);
+      }
+      key = (uint16_t)(acgt ? code : FILL_BUCKETS);
+      atomicAdd(&p.fill_hist[key], 1u);
+    }
+    p.fill_keys[tid] = key;
+  }
+}
+// cursors = exclusive scan of the counts (one workgroup of 1024 threads), total behind them
+__global__ __launch_bounds__(1024) void seed_fill_scan_kernel(unsigned int* hist) {
+  __shared__ unsigned part[1024];
+  constexpr unsigned NB = FILL_BUCKETS + 1, PER = (NB + 1023) / 1024;
+  const unsigned t = threadIdx.x, b0 = t * PER;
+  unsigned sum = 0;
+  for (unsigned k = 0; k < PER; k++)
+    if (b0 + k < NB) sum += hist[b0 + k];
+  part[t] = sum;
+  __syncthreads();
+  for (unsigned o = 1; o < 1024; o <<= 1) {  // inclusive scan of the per-thread sums
+    const unsigned v = t >= o ? part[t - o] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned run = part[t] - sum;
+  unsigned int* cursor = hist + NB;
+  for (unsigned k = 0; k < PER; k++)
+    if (b0 + k < NB) {
+      cursor[b0 + k] = run;
+      run += hist[b0 + k];
+    }
+  if (t == 1023) hist[2 * NB] = part[1023];
+}
+template <class C>
+__global__ __launch_bounds__(256) void seed_fill_scatter_kernel(SeedParamsT<C> p) {
+  const uint64_t total = p.work_counts[1] * PROBE_STRIDE;
+  const uint64_t step = (uint64_t)gridDim.x * 256;
+  unsigned int* cursor = p.fill_hist + (FILL_BUCKETS + 1);
+  for (uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x; tid < total; tid += step) {
+    const uint16_t key = p.fill_keys[tid];
+    if (key != 0xFFFF) p.fill_perm[atomicAdd(&cursor[key], 1u)] = (uint32_t)tid;
+  }
+}
+template <class C>
+__global__ __launch_bounds__(256) void seed_fill_bucketed_kernel(SeedParamsT<C> p) {
+  const uint64_t total = p.fill_hist[2 * (FILL_BUCKETS + 1)];
+  const uint64_t step = (uint64_t)gridDim.x * 256;
+  for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < total; s += step) {
+    const uint64_t tid = p.fill_perm[s];
+    uint64_t read, r0;
+    int pos, L;
+    if (fill_item(p, tid, read, pos, r0, L)) fill_probe(p, read, pos, r0, L);
+  }
 }
 
 // per read: SMEM selection and ordering, one read per wavefront.  The per-read lists (one entry per
@@ -860,7 +943,16 @@ static hipError_t launch_seed_t(const SeedParamsT<C>& p, int n_blocks, hipStream
     fill_cells += c.n * NC;
   }
   if (fill_cells) {
-    hipLaunchKernelGGL(dev::seed_fill_kernel<C>, blocks(fill_cells * dev::PROBE_STRIDE), dim3(256), 0, s, p);
+    const dim3 worst = blocks(fill_cells * dev::PROBE_STRIDE);
+    const dim3 fixed(std::min<unsigned>(worst.x, 256u * 8u * 4u));  // (8 workgroups per CU, four times over)
+    if (p.fill_mode == 2 && fill_cells * dev::PROBE_STRIDE < (1ull << 32)) {
+      hipLaunchKernelGGL(dev::seed_fill_keys_kernel<C>, fixed, dim3(256), 0, s, p);
+      hipLaunchKernelGGL(dev::seed_fill_scan_kernel, dim3(1), dim3(1024), 0, s, p.fill_hist);
+      hipLaunchKernelGGL(dev::seed_fill_scatter_kernel<C>, fixed, dim3(256), 0, s, p);
+      hipLaunchKernelGGL(dev::seed_fill_bucketed_kernel<C>, fixed, dim3(256), 0, s, p);
+    } else {
+      hipLaunchKernelGGL(dev::seed_fill_kernel<C>, p.fill_mode == 1 ? fixed : worst, dim3(256), 0, s, p);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   // SMEM selection: short reads one per thread, its overflow list and the long reads through the

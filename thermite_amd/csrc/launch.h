@@ -82,7 +82,16 @@ struct SeedParamsT {
   int* fault;  // 1 = smem pool overflow
   uint8_t* sel_scratch;        // global scratch of the wavefront-per-read selection when its lists do not fit LDS
   uint64_t sel_scratch_per_wave;
+  // seed_fill_kernel's probes (THM_SEED_FILL): 0 = one thread per slot of the worst-case grid, 1 = a fixed grid striding
+  // over the listed cells, 2 = the probes bucketed by the leading FILL_KEY_BASES bases of their k-mer first (the
+  // probe-ordering experiment of DESIGN.md section 4.1: table and suffix-array reads of a wave become neighbours)
+  uint32_t fill_mode;
+  uint16_t* fill_keys;     // [fill slots] bucket of the probe, 0xFFFF: no probe
+  uint32_t* fill_perm;     // [fill slots] probes in bucket order
+  unsigned int* fill_hist; // [FILL_BUCKETS] counts, [FILL_BUCKETS] cursors, [1] total; zeroed before launch
 };
+constexpr int FILL_KEY_BASES = 7;
+constexpr unsigned FILL_BUCKETS = 1u << (2 * FILL_KEY_BASES);  // + one bucket for k-mers with a byte outside ACGT
 size_t seed_select_lds_bytes(uint32_t max_read_len);         // per workgroup (4 waves)
 size_t seed_select_scratch_bytes(uint32_t max_read_len);     // per wave
 constexpr size_t SEED_SELECT_LDS_LIMIT = 64 * 1024;          // above this the lists go to global scratch

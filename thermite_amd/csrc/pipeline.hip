@@ -137,6 +137,25 @@ int enqueue_seed_t(thm_aligner* a, uint32_t min_seed_len) {
   sp.fault = a->d_fault.as<int>();
   sp.sel_scratch = nullptr;
   sp.sel_scratch_per_wave = 0;
+  static const uint32_t fill_mode = [] {
+    const char* e = getenv("THM_SEED_FILL");
+    const int v = e ? atoi(e) : 0;
+    return (uint32_t)(v >= 0 && v <= 2 ? v : 0);
+  }();
+  sp.fill_mode = fill_mode;
+  sp.fill_keys = nullptr;
+  sp.fill_perm = nullptr;
+  sp.fill_hist = nullptr;
+  if (fill_mode == 2) {
+    const uint64_t slots = (std::max(cells, n) + 1) * 8;
+    HIPCHK(a, a->s_fill_keys.ensure(slots * 2));
+    HIPCHK(a, a->s_fill_perm.ensure(slots * 4));
+    HIPCHK(a, a->s_fill_hist.ensure((2 * (FILL_BUCKETS + 1) + 1) * 4));
+    HIPCHK(a, hipMemsetAsync(a->s_fill_hist.p, 0, (2 * (FILL_BUCKETS + 1) + 1) * 4, s));
+    sp.fill_keys = a->s_fill_keys.as<uint16_t>();
+    sp.fill_perm = a->s_fill_perm.as<uint32_t>();
+    sp.fill_hist = a->s_fill_hist.as<unsigned int>();
+  }
   if (n_long && seed_select_lds_bytes(max_long) > SEED_SELECT_LDS_LIMIT) {
     // reads of thousands of bases: the selection kernel's per-read lists go to global memory
     const int nb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_blocks, (n_long + 3) / 4));
