@@ -72,6 +72,18 @@ except OSError:
 print("each .gz: %d reads in %d member(s), %.1f MB; host: %d hardware threads, cpu.max %s" % (n * REP, REP, os.path.getsize(gz) / 1e6, os.cpu_count(), quota), flush=True)
 
 
+def digest(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+paf_of_plain = digest("/tmp/thm_e2e_out.paf")  # (the last plain run wrote PAF of the REP-copy file)
+
+
 def run(tag, paths, fmt, out):
     for rep in range(2):
         st = capi.align_files(a, paths, out, fmt, batch_reads=250000, n_threads=threads)
@@ -81,6 +93,10 @@ def run(tag, paths, fmt, out):
 
 
 run("paf from one .gz", [gz], capi.FMT_PAF, "/tmp/thm_e2e_out.paf")
+# the .gz holds the same records as the plain file (REP members of the same reads): same PAF, byte for byte
+same = digest("/tmp/thm_e2e_out.paf") == paf_of_plain
+print("PAF of the .gz input %s the PAF of the plain input (sha256 over %d reads)" % ("EQUALS" if same else "DIFFERS FROM", n * REP), flush=True)
+assert same
 run("paf from two .gz", [gz, gz2], capi.FMT_PAF, "/tmp/thm_e2e_out.paf")
 run("bam from plain fastq", [big], capi.FMT_BAM, "/tmp/thm_e2e_out.bam")
 run("bam from two .gz", [gz, gz2], capi.FMT_BAM, "/tmp/thm_e2e_out.bam")
