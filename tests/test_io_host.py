@@ -619,3 +619,24 @@ def test_parallel_inflate_reader_closed_early(tmp_path, monkeypatch):
         assert len(b["offsets"]) == 101
         r.close()
     assert len(os.listdir("/proc/self/task")) <= n_os and threading.active_count() == before
+
+
+def test_parallel_inflate_gives_up_on_endless_segments(tmp_path, monkeypatch):
+    """a stream in which no block start can be found (stored blocks only, fixed-Huffman blocks only) would be decoded as
+    one segment of 16-bit symbols as long as the whole output: beyond a bound the parallel decoder hands the file to
+    the serial one -- same bytes, constant memory"""
+    import zlib
+    monkeypatch.setenv("THM_INFLATE_CHUNK_KB", "16")
+    monkeypatch.setenv("THM_INFLATE_MAX_SEGMENT_MB", "1")
+    fq = _big_fastq(30000, 29)
+    p = tmp_path / "stored.gz"
+    p.write_bytes(gzip.compress(fq, 0))
+    assert capi.debug_gunzip(p, 1 << 16, threads=3) == fq
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+    p = tmp_path / "fixed.gz"
+    p.write_bytes(co.compress(fq) + co.flush())
+    assert capi.debug_gunzip(p, 1 << 16, threads=3) == fq
+    # ... and a normal stream under the same bound still decodes in parallel segments or serially, to the same bytes
+    p = tmp_path / "dyn.gz"
+    p.write_bytes(gzip.compress(fq, 6))
+    assert capi.debug_gunzip(p, 1 << 16, threads=3) == fq

@@ -875,6 +875,7 @@ struct GzInflater::Par {
   uint64_t to_resolve = 0;  // next segment in stream order waiting for its window
   std::vector<uint8_t> window;  // last 32 KiB before segment `to_resolve`
   unsigned inflight = 0, max_inflight = 0;  // segments between the start of their decoding and the consumer
+  size_t max_segment = (size_t)192 << 20;   // symbols one segment may grow to (THM_INFLATE_MAX_SEGMENT_MB for the tests)
   uint32_t crc = 0;
   uint64_t member_out = 0;
   bool finished = false;
@@ -1071,6 +1072,10 @@ struct GzInflater::Par {
         std::lock_guard<std::mutex> g(mu);
         if (cancel) ok = false;
       }
+      // A stream without block starts to find (stored or fixed-Huffman blocks only, or one endless block) would
+      // become ONE segment of symbols, two bytes per output byte: beyond a bound the segment is given up and the
+      // serial decoder takes the rest of the file, window known, in constant memory.
+      if (n > max_segment) ok = d->fail("segment too long for the parallel decoder");
     }
     if (at_end && c->stop_bit) ok = false;  // the stream ended before the start the next segment was given
     {
@@ -1227,6 +1232,7 @@ bool GzInflater::open_parallel(int fd, const std::string& path, unsigned n_threa
   par->lookahead = 4 * n_threads + 4;  // starts are searched this many chunks ahead (a search holds no buffer)
   par->max_inflight = n_threads + 2;   // segments being decoded, resolved or waiting for the consumer (they hold the buffers)
   par->window.assign(WINDOW, 0);
+  if (const char* e = getenv("THM_INFLATE_MAX_SEGMENT_MB")) par->max_segment = (size_t)std::max(1L, atol(e)) << 20;
   // the first member's header: the first segment starts at its first block
   Impl h;
   h.open_memory(par->base, size, path);
