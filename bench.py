@@ -120,8 +120,8 @@ def profile_entry(name, match):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=48)  # 0.27 s of timed region at N = 1 (12 steps were 0.07 s)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--reads-per-gpu", type=int, default=None, help="weak scaling: this many reads per rank (default at N = 1: 500 000)")
     ap.add_argument("--total-reads", type=int, default=None, help="strong scaling: one stream of this many reads sharded over the ranks "
                                                                     "(default at N > 1: 50 000 000, BASELINE configs[3])")
