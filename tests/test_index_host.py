@@ -91,11 +91,15 @@ def test_kmer_table_by_counting_equals_table_from_suffix_array(data_dir, wide, m
             monkeypatch.delenv("THM_KT", raising=False)
         else:
             monkeypatch.setenv("THM_KT", str(kt))
-        for t in tabs:
-            ix = capi.Index(t, wide=wide)
-            assert ix.coord_bytes == (8 if wide else 4)
-            assert ix.check_lut(), (kt, len(t["text"]))
-            ix.close()
+        # the counting runs on several threads for big texts: ranges that start and end inside a run, at a run's
+        # first or last symbol, on separators (THM_INDEX_THREADS forces them on these small texts)
+        for threads in (1, 2, 3, 7, 16):
+            monkeypatch.setenv("THM_INDEX_THREADS", str(threads))
+            for t in tabs:
+                ix = capi.Index(t, wide=wide)
+                assert ix.coord_bytes == (8 if wide else 4)
+                assert ix.check_lut(), (kt, threads, len(t["text"]))
+                ix.close()
 
 
 def test_wide_index_tables_and_file_round_trip(data_dir, tmp_path, monkeypatch):

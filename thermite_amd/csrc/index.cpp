@@ -15,9 +15,12 @@
 // Pure host C++ (no HIP); device upload lives in aligner.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -239,39 +242,35 @@ void build_lut(thm_index* ix, std::vector<LutEntryT<C>>& lut) {
   // counted in place: lut[c].hi = occurrences of c, lut[c].lo = suffixes of the second kind with threshold c
   // (a threshold past the last code precedes nothing and is dropped)
   lut.assign(nk, LutEntryT<C>{0, 0});
-  auto dirty_at = [&](uint64_t T) {
-    if (T < nk) lut[T].lo++;
-  };
   const uint8_t* text = ix->text.data();
-  // the text is cut into maximal ACGT runs [a, b) (b = first position outside ACGT, or n); each run is handled on its own
-  {
-    uint64_t a = 0;
-    while (a < n) {
-      if (base_code(text[a]) < 0) {  // a suffix that starts outside ACGT: m = 0, u empty, x = text[a]
-        const uint8_t x = text[a];
-        const uint64_t T = x < 'A' ? 0 : x < 'C' ? (1ull << (2 * (kt - 1))) : x < 'G' ? (2ull << (2 * (kt - 1)))
-                           : x < 'T' ? (3ull << (2 * (kt - 1))) : nk;
-        dirty_at(T);
-        a++;
-        continue;
-      }
-      uint64_t b = a;
-      while (b < n && base_code(text[b]) >= 0) b++;
-      const bool at_end = b >= n;
-      const uint8_t x = at_end ? 0 : text[b];  // end of text: smaller than every symbol
-      // rolling code over the run
-      uint64_t code = 0;
-      const uint64_t mask = nk - 1;
-      for (uint64_t p = a; p < b; p++) {
-        code = ((code << 2) | (uint64_t)base_code(text[p])) & mask;
-        if (p + 1 - a >= kt) lut[code].hi++;  // the kt-mer starting at p + 1 - kt
-      }
-      // the last min(kt - 1, b - a) positions of the run start a suffix with m < kt ACGT symbols
-      const uint64_t first_dirty = (b - a >= kt) ? b - (kt - 1) : a;
-      for (uint64_t p = first_dirty; p < b; p++) {
-        const uint32_t m = (uint32_t)(b - p);
+  // Counting, over the text in parallel: thread t owns the positions [s, e) of its range -- it counts the kt-mers that
+  // END there, and handles every run end and every non-ACGT position inside.  The text is cut into maximal ACGT runs
+  // [a, b) (b = first position outside ACGT, or n); a range that starts inside a run recovers what it needs of the run
+  // before it by looking back kt - 1 symbols.  Increments are relaxed atomics on the table (the counts do not
+  // depend on the order).
+  auto add_hi = [&](uint64_t c) { __atomic_fetch_add(&lut[c].hi, (C)1, __ATOMIC_RELAXED); };
+  auto add_lo = [&](uint64_t T) {
+    if (T < nk) __atomic_fetch_add(&lut[T].lo, (C)1, __ATOMIC_RELAXED);
+  };
+  auto count_range = [&](uint64_t s, uint64_t e) {
+    const uint64_t mask = nk - 1;
+    uint64_t p = s;
+    // the part of a run that lies before s, as far as it matters: `have` symbols (at most kt - 1) and their code
+    uint64_t have = 0, code = 0;
+    if (s < n && base_code(text[s]) >= 0) {
+      while (have < kt - 1 && have < s && base_code(text[s - 1 - have]) >= 0) have++;
+      for (uint64_t q = s - have; q < s; q++) code = ((code << 2) | (uint64_t)base_code(text[q])) & mask;
+    }
+    // the run that ends at bnd (its first symbol outside ACGT, or the end of the text): its last min(kt - 1, length)
+    // positions start a suffix with m < kt ACGT symbols.  Whoever owns bnd handles them, wherever they lie.
+    auto run_end = [&](uint64_t bnd) {
+      const uint8_t x = bnd >= n ? 0 : text[bnd];  // end of text: smaller than every symbol
+      uint64_t back = 0;
+      while (back < kt - 1 && back < bnd && base_code(text[bnd - 1 - back]) >= 0) back++;
+      for (uint64_t d0 = bnd - back; d0 < bnd; d0++) {
+        const uint32_t m = (uint32_t)(bnd - d0);
         uint64_t u = 0;
-        for (uint64_t q = p; q < b; q++) u = (u << 2) | (uint64_t)base_code(text[q]);
+        for (uint64_t r = d0; r < bnd; r++) u = (u << 2) | (uint64_t)base_code(text[r]);
         const uint32_t rest = kt - m;  // symbols of a code after u; >= 1
         uint64_t T;
         if (x < 'A')
@@ -284,9 +283,42 @@ void build_lut(thm_index* ix, std::vector<LutEntryT<C>>& lut) {
           T = ((u << 2) | 3) << (2 * (rest - 1));
         else
           T = (u + 1) << (2 * rest);
-        dirty_at(T);
+        add_lo(T);
       }
-      a = b;
+    };
+    while (p < e) {
+      if (base_code(text[p]) < 0) {  // a suffix that starts outside ACGT: m = 0, u empty, x = text[p]
+        run_end(p);  // (nothing to do when text[p - 1] is outside ACGT too)
+        const uint8_t x = text[p];
+        const uint64_t T = x < 'A' ? 0 : x < 'C' ? (1ull << (2 * (kt - 1))) : x < 'G' ? (2ull << (2 * (kt - 1)))
+                           : x < 'T' ? (3ull << (2 * (kt - 1))) : nk;
+        add_lo(T);
+        p++;
+        have = 0;
+        code = 0;
+        continue;
+      }
+      // inside a run: roll on to its end, or to the end of the range
+      uint64_t q = p;
+      while (q < e && base_code(text[q]) >= 0) {
+        code = ((code << 2) | (uint64_t)base_code(text[q])) & mask;
+        if (have + 1 >= kt) add_hi(code);  // the kt-mer ending at q
+        else have++;
+        q++;
+      }
+      if (q == n) run_end(n);  // the run ends with the text
+      p = q;
+    }
+  };
+  {
+    unsigned T = (unsigned)std::min<uint64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n / (4u << 20) + 1);
+    if (const char* e = getenv("THM_INDEX_THREADS")) T = (unsigned)std::max(1, std::min(64, atoi(e)));
+    if (T <= 1) {
+      count_range(0, n);
+    } else {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < T; t++) th.emplace_back(count_range, n * t / T, n * (t + 1) / T);
+      for (auto& x : th) x.join();
     }
   }
   uint64_t before = 0;  // suffixes that sort before code c
@@ -472,15 +504,26 @@ static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref*
     if (sizeof(C) == 4) return build_suffix_array(text, n, (uint32_t*)dst.data()) == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
     return build_suffix_array64(text, n, (uint64_t*)dst.data()) == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
   };
+  // THM_INDEX_TIMING=1: seconds per phase of the build on stderr (tools/big_text.py --index-timing)
+  const bool timing = getenv("THM_INDEX_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto lap = [&](const char* what, std::chrono::steady_clock::time_point& t0) {
+    const auto t1 = now();
+    if (timing) fprintf(stderr, "thm_index_create: %-28s %8.2f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
+  auto t_phase = now();
   const int src = wide ? fill_sa(ix->sa64) : fill_sa(ix->sa);
   if (src != THM_OK) {
     delete ix;
     return src;
   }
+  lap(sa ? "suffix array (checked)" : "suffix array (SA-IS)", t_phase);
   if (wide)
     build_lut<uint64_t>(ix, ix->lut64);
   else
     build_lut<uint32_t>(ix, ix->lut);
+  lap("k-mer table", t_phase);
 
   // exon_to_tx: src/index.rs:164-191 inserts each transcript's exons in the
   // order the annotation lists them (genomic order) BEFORE reversing the
@@ -515,6 +558,7 @@ static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref*
     build_exon_grid<uint32_t>(ix, ix->exon_grid_off, ix->exon_grid);
     build_grid<uint32_t>(ix->gene_tree, ix->gene_root, n, ix->gene_grid_off, ix->gene_grid);
   }
+  lap("interval trees and grids", t_phase);
   // idx_to_ref as two loads (thermite_internal.h, RefRecT)
   {
     const uint64_t nbins = (n >> GRID_SHIFT) + 1;
