@@ -103,7 +103,7 @@ ABI_SYMBOLS = [
     "thm_batch_sync", "thm_batch_fetch", "thm_smems_batch", "thm_swg_extend_batch", "thm_counters_get",
     "thm_counters_reset", "thm_counters_device_ptr", "thm_timings_get", "thm_version", "thm_device_count",
     "thm_aligner_index", "thm_comm_unique_id", "thm_comm_create", "thm_comm_free", "thm_counters_allreduce",
-    "thm_index_create_in_memory_ex", "thm_index_coord_bytes", "thm_index_suffix_array64", "thm_build_suffix_array64",
+    "thm_index_create_in_memory_ex", "thm_index_coord_bytes", "thm_index_suffix_array64", "thm_build_suffix_array64", "thm_build_suffix_array_gpu",
 ]
 # every symbol include/thermite_io.h declares
 IO_ABI_SYMBOLS = [
@@ -137,6 +137,8 @@ def lib():
     L.thm_index_suffix_array64.argtypes = [vp]
     L.thm_build_suffix_array64.restype = i32
     L.thm_build_suffix_array64.argtypes = [vp, u64, vp]
+    L.thm_build_suffix_array_gpu.restype = i32
+    L.thm_build_suffix_array_gpu.argtypes = [vp, u64, vp, u32]
     if hasattr(L, "thm_debug_check_lut"):
         L.thm_debug_check_lut.restype = i32
         L.thm_debug_check_lut.argtypes = [vp]
@@ -273,6 +275,17 @@ def _u8(b):
     if isinstance(b, np.ndarray):
         return np.ascontiguousarray(b, np.uint8)
     return np.frombuffer(bytes(b), np.uint8)
+
+
+def build_suffix_array_gpu(text, wide=False):
+    """the suffix array of `text` built on the current HIP device (thm_build_suffix_array_gpu); raises ThermiteError
+    with ERR_NO_DEVICE / ERR_OOM / ERR_UNSUPPORTED when the host builder has to do it"""
+    text = np.ascontiguousarray(text, np.uint8)
+    out = np.empty(len(text), "<u8" if wide else "<u4")
+    rc = lib().thm_build_suffix_array_gpu(_ptr(text), len(text), _ptr(out), 8 if wide else 4)
+    if rc != 0:
+        raise ThermiteError(rc, _last_error())
+    return out
 
 
 def build_suffix_array(text, wide=False):

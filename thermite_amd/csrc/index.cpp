@@ -479,6 +479,7 @@ static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref*
   ix->genes.assign(genes, genes + n_genes);
 
   // suffix array in the index's width (a supplied array is checked, and converted when its width differs)
+  bool sa_on_gpu = false;
   auto fill_sa = [&](auto& dst) -> int {
     typedef typename std::remove_reference<decltype(dst)>::type::value_type C;
     dst.resize(n);
@@ -501,6 +502,11 @@ static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref*
       }
       return THM_OK;
     }
+    // on the GPU where there is one (sa_gpu.hip: seconds against minutes); the host builder otherwise
+    if (n >= (4u << 20) && !getenv("THM_SA_HOST") && build_suffix_array_gpu(text, n, dst.data(), (int)sizeof(C)) == 0) {
+      sa_on_gpu = true;
+      return THM_OK;
+    }
     if (sizeof(C) == 4) return build_suffix_array(text, n, (uint32_t*)dst.data()) == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
     return build_suffix_array64(text, n, (uint64_t*)dst.data()) == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
   };
@@ -518,7 +524,7 @@ static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref*
     delete ix;
     return src;
   }
-  lap(sa ? "suffix array (checked)" : "suffix array (SA-IS)", t_phase);
+  lap(sa ? "suffix array (checked)" : sa_on_gpu ? "suffix array (GPU)" : "suffix array (SA-IS)", t_phase);
   if (wide)
     build_lut<uint64_t>(ix, ix->lut64);
   else

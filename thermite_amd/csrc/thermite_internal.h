@@ -129,6 +129,9 @@ bool verify_suffix_array(const uint8_t* text, uint64_t n, const C* sa);
 
 void set_global_error(const std::string& msg);
 
+// sa_gpu.hip: suffix array by prefix doubling on the current HIP device; nonzero: sort on the host instead
+int build_suffix_array_gpu(const uint8_t* text, uint64_t n, void* out, int elem_bytes);
+
 }  // namespace thm
 
 // Host index: owns the tables; device copies are created lazily per device.
