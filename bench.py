@@ -53,19 +53,6 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def load_suffix_array(capi, tables, rank, world, dist, tag):
-    """Rank 0 builds the suffix array once and shares it through /tmp."""
-    path = "/tmp/thm_bench_sa_%s.npy" % tag
-    if rank == 0 and not os.path.exists(path):
-        sa = capi.build_suffix_array(tables["text"])
-        tmp = path + ".%d.tmp.npy" % os.getpid()
-        np.save(tmp, sa)
-        os.replace(tmp, path)
-    if world > 1:
-        dist.barrier()
-    return np.load(path, mmap_mode="r")
-
-
 def stream_reads(synth, tables, begin, end, L):
     """Reads [begin, end) of the global seeded stream, generated chunk by chunk (only the chunks the range touches)."""
     parts = []
@@ -194,8 +181,8 @@ def main():
         ref_len = args.ref_len or synth.CHR21_LEN
         tables = synth.synth_reference(length=ref_len)
         tag = "%d_%x" % (ref_len, synth.SEED)
-    sa = load_suffix_array(capi, tables, rank, world, dist, tag)
-    index = capi.Index(tables, sa=sa, wide=args.wide)
+    # (no suffix array supplied: every rank's library sorts the suffixes on its own GPU, csrc/sa_gpu.hip -- 0.4 s here)
+    index = capi.Index(tables, wide=args.wide)
     t_index = time.time() - t0
     log(rank, "reference: %s %d bp, text n=%d, %d transcripts, %d exons; index (%d-byte coordinates) in %.1fs" % (
         args.workload, ref_len, len(tables["text"]), len(tables["txs"]), len(tables["exons"]), index.coord_bytes, time.time() - t0))
@@ -407,7 +394,7 @@ def main():
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         cores = min(cores, 16)  # a one-GPU box owns a 16-thread share of the host
         t1 = time.time()
-        oix = orc.Index(tables, sa=sa)
+        oix = orc.Index(tables, sa=index.suffix_array())
         log(rank, "oracle index (BWT/Occ/sampled SA) in %.1fs; timing on %d host threads" % (time.time() - t1, cores))
         probe = min(2000 * cores, reads_this_rank)
         t1 = time.perf_counter()
