@@ -31,6 +31,16 @@ def test_device_suffix_array_equals_the_host_builder(data_dir):
             assert np.array_equal(got.astype(np.uint64), want.astype(np.uint64)), (len(text), wide)
 
 
+def test_wide_device_builder_equals_the_host_builder(data_dir, monkeypatch):
+    """texts of 2^32 - 2 symbols and more take a second device builder (64-bit positions, a round = two stable sorts
+    because a pair of ranks no longer fits one key); THM_SA_WIDE_SORT=1 sends small texts through it"""
+    monkeypatch.setenv("THM_SA_WIDE_SORT", "1")
+    for text in _texts(data_dir):
+        want = capi.build_suffix_array(text)
+        got = capi.build_suffix_array_gpu(text, wide=True)
+        assert np.array_equal(got, want.astype(np.uint64)), len(text)
+
+
 def test_index_without_a_supplied_suffix_array_builds_it_on_the_device(monkeypatch):
     t = synth.synth_reference(length=3_000_000)  # 6 M symbols: above the threshold of the device builder
     assert len(t["text"]) >= (4 << 20)

@@ -63,6 +63,47 @@ __global__ void sa_widen(const uint32_t* in, uint64_t n, uint64_t* out) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) out[i] = in[i];
 }
 
+// ---- texts of 2^32 - 2 symbols and more: 64-bit positions, ranks of 33 bits and more.  The pair (rank[i], rank[i + h])
+// no longer fits one 64-bit key, so a round is two stable sorts -- by the second component, then by the first.
+__global__ void saw_first_keys(const uint8_t* text, uint64_t n, uint64_t* key, uint64_t* val) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    uint64_t k = 0;
+    for (int b = 0; b < 8; b++) k = (k << 8) | (i + b < n ? (uint64_t)text[i + b] : 0ull);
+    key[i] = k;
+    val[i] = i;
+  }
+}
+// head[i] = i where (a[i], b[i]) differs from the entry before (b may be null: one component), else 0
+__global__ void saw_group_heads(const uint64_t* a, const uint64_t* b, uint64_t n, uint64_t* head, unsigned long long* distinct) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long mine = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const bool h = i == 0 || a[i] != a[i - 1] || (b && b[i] != b[i - 1]);
+    head[i] = h ? i : 0ull;
+    mine += h;
+  }
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(distinct, mine);
+}
+__global__ void saw_scatter_ranks(const uint64_t* pos, const uint64_t* rank_sorted, uint64_t n, uint64_t* rank_at) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) rank_at[pos[i]] = rank_sorted[i];
+}
+// key[i] = rank behind position pos[i] + h (pos == null: position i), 0 behind the end; val[i] = i when asked for
+__global__ void saw_second_keys(const uint64_t* rank_at, const uint64_t* pos, uint64_t n, uint64_t h, uint64_t* key, uint64_t* val) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const uint64_t q = (pos ? pos[i] : i) + h;
+    key[i] = q < n ? rank_at[q] + 1 : 0ull;
+    if (val) val[i] = i;
+  }
+}
+__global__ void saw_first_of(const uint64_t* rank_at, const uint64_t* pos, uint64_t n, uint64_t* key) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) key[i] = rank_at[pos[i]];
+}
+
 struct DeviceArrays {  // freed whatever way the builder leaves
   void* p[10] = {nullptr};
   int n = 0;
@@ -79,16 +120,93 @@ struct DeviceArrays {  // freed whatever way the builder leaves
 
 }  // namespace
 
+// the wide builder: 64-bit entries out, 41 bytes of device memory per symbol
+static int build_suffix_array_gpu_wide(const uint8_t* text, uint64_t n, uint64_t* out) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 42 + (512u << 20)) return -3;
+#define SA_CK(x)                    \
+  do {                              \
+    if ((x) != hipSuccess) {        \
+      (void)hipGetLastError();      \
+      return -4;                    \
+    }                               \
+  } while (0)
+  DeviceArrays mem;
+  uint8_t* d_text = nullptr;
+  uint64_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *rank_at = nullptr;
+  unsigned long long* d_distinct = nullptr;
+  void* tmp = nullptr;
+  SA_CK(mem.alloc(&d_text, n + 8));
+  SA_CK(mem.alloc(&k0, n * 8));
+  SA_CK(mem.alloc(&k1, n * 8));
+  SA_CK(mem.alloc(&v0, n * 8));
+  SA_CK(mem.alloc(&v1, n * 8));
+  SA_CK(mem.alloc(&rank_at, n * 8));
+  SA_CK(mem.alloc(&d_distinct, 8));
+  SA_CK(hipMemcpy(d_text, text, n, hipMemcpyHostToDevice));
+  int rank_bits = 1;
+  while (rank_bits < 64 && (n >> rank_bits) != 0) rank_bits++;
+  rank_bits++;  // (ranks go up to n - 1, second components up to n)
+  size_t sort_bytes = 0, scan_bytes = 0;
+  SA_CK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k0, k1, v0, v1, n, 0, 64));
+  SA_CK(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, k0, v0, hipcub::Max(), n));
+  const size_t tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  SA_CK(mem.alloc((uint8_t**)&tmp, tmp_bytes));
+  const dim3 grid(256 * 16), block(256);
+  auto distinct_after = [&](const uint64_t* a, const uint64_t* b, uint64_t* head, unsigned long long& distinct) -> hipError_t {
+    hipError_t e = hipMemsetAsync(d_distinct, 0, 8, 0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(saw_group_heads, grid, block, 0, 0, a, b, n, head, d_distinct);
+    return hipMemcpy(&distinct, d_distinct, 8, hipMemcpyDeviceToHost);
+  };
+  // round 0: by the first 8 bytes
+  hipLaunchKernelGGL(saw_first_keys, grid, block, 0, 0, d_text, n, k0, v0);
+  size_t sb = tmp_bytes;
+  SA_CK(hipcub::DeviceRadixSort::SortPairs(tmp, sb, k0, k1, v0, v1, n, 0, 64));
+  uint64_t* pos = v1;  // positions in the current order
+  unsigned long long distinct = 0;
+  SA_CK(distinct_after(k1, nullptr, k0, distinct));  // heads -> k0
+  for (uint64_t h = 8; distinct != n; h *= 2) {
+    if (h >= n) return -5;
+    // ranks of the current order (max-scan of the heads in k0), scattered to text order
+    uint64_t* rs = pos == v1 ? v0 : v1;
+    sb = tmp_bytes;
+    SA_CK(hipcub::DeviceScan::InclusiveScan(tmp, sb, k0, rs, hipcub::Max(), n));
+    hipLaunchKernelGGL(saw_scatter_ranks, grid, block, 0, 0, pos, rs, n, rank_at);
+    // A: by the second component, from text order
+    hipLaunchKernelGGL(saw_second_keys, grid, block, 0, 0, rank_at, (const uint64_t*)nullptr, n, h, k0, v0);
+    sb = tmp_bytes;
+    SA_CK(hipcub::DeviceRadixSort::SortPairs(tmp, sb, k0, k1, v0, v1, n, 0, rank_bits));  // -> k1 (second), v1 (positions)
+    // B: stable, by the first component
+    hipLaunchKernelGGL(saw_first_of, grid, block, 0, 0, rank_at, v1, n, k0);
+    sb = tmp_bytes;
+    SA_CK(hipcub::DeviceRadixSort::SortPairs(tmp, sb, k0, k1, v1, v0, n, 0, rank_bits));  // -> k1 (first), v0 (positions)
+    pos = v0;
+    // groups of equal (first, second): the second components once more, in the new order (-> k0), heads -> v1
+    hipLaunchKernelGGL(saw_second_keys, grid, block, 0, 0, rank_at, pos, n, h, k0, (uint64_t*)nullptr);
+    SA_CK(distinct_after(k1, k0, v1, distinct));
+    // (the heads go where the loop expects them)
+    SA_CK(hipMemcpyAsync(k0, v1, n * 8, hipMemcpyDeviceToDevice, 0));
+  }
+  SA_CK(hipMemcpy(out, pos, n * 8, hipMemcpyDeviceToHost));
+  SA_CK(hipDeviceSynchronize());
+#undef SA_CK
+  return 0;
+}
+
 // 0: out[0, n) holds the suffix array (entries of elem_bytes = 4 or 8 bytes).  Anything else: nothing was written that
 // counts -- no device, not enough device memory, a text too long for 32-bit ranks, a HIP error -- the caller sorts on the host.
 int build_suffix_array_gpu(const uint8_t* text, uint64_t n, void* out, int elem_bytes) {
   if (n == 0) return 0;
-  if (n >= 0xFFFFFFFEull || (elem_bytes != 4 && elem_bytes != 8)) return -2;
+  if (elem_bytes != 4 && elem_bytes != 8) return -2;
+  if (n >= 0xFFFFFFFEull && elem_bytes != 8) return -2;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
     (void)hipGetLastError();
     return -1;
   }
+  // (THM_SA_WIDE_SORT=1: the wide builder on a small text too -- how the tests reach it)
+  if (n >= 0xFFFFFFFEull || (elem_bytes == 8 && getenv("THM_SA_WIDE_SORT"))) return build_suffix_array_gpu_wide(text, n, (uint64_t*)out);
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 38 + (256u << 20)) return -3;
 #define SA_CK(x)                    \
