@@ -270,7 +270,7 @@ int32_t thm_build_suffix_array(const uint8_t* text, uint64_t n, uint32_t* sa_out
 int32_t thm_build_suffix_array64(const uint8_t* text, uint64_t n, uint64_t* sa_out);
 /* the same array built on the current HIP device (prefix doubling over a radix sort: seconds where the host builder
  * takes minutes); sa_out holds n entries of elem_bytes = 4 or 8 bytes.  THM_ERR_NO_DEVICE / THM_ERR_OOM /
- * THM_ERR_UNSUPPORTED (2^32 - 2 symbols and more): use the host builders.  thm_index_create_* without a supplied
+ * THM_ERR_UNSUPPORTED (2^32 - 2 symbols and more with 4-byte entries): use the host builders.  thm_index_create_* without a supplied
  * suffix array tries this first for texts of 4 Mi symbols and more (THM_SA_HOST=1 in the environment: never). */
 int32_t thm_build_suffix_array_gpu(const uint8_t* text, uint64_t n, void* sa_out, uint32_t elem_bytes);
 
