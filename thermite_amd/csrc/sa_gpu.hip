@@ -12,8 +12,9 @@
 // library also accepts only verified arrays from outside).  Every round sorts all n pairs, no group bookkeeping:
 // log2(longest repeat / 8) + 1 rounds of one 64-bit radix sort (a run of 118 M `N` makes it 25 rounds).  Measured:
 // 93 M symbols 0.2 s, 600 M 1.6 s, 2.2 G 6.7 s with the transfers, against 7 s, 55 s and 190 s of single-threaded
-// induced sorting on the host.  36 bytes of device memory per symbol while it runs; texts of 2^32 - 2 symbols and
-// more, hosts without a device and devices without that much free memory take the host builder.
+// induced sorting on the host.  36 bytes of device memory per symbol while it runs (41 in the wide builder below, for
+// texts of 2^32 - 2 symbols and more: 4.4 G symbols in 35 s); hosts without a device and devices without that much free
+// memory take the host builder.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -276,7 +277,7 @@ extern "C" int32_t thm_build_suffix_array_gpu(const uint8_t* text, uint64_t n, v
     return THM_ERR_NO_DEVICE;
   }
   if (rc == -2) {
-    thm::set_global_error("thm_build_suffix_array_gpu: texts of 2^32 - 2 symbols and more are sorted on the host (thm_build_suffix_array64)");
+    thm::set_global_error("thm_build_suffix_array_gpu: a text of 2^32 - 2 symbols and more needs 8-byte entries");
     return THM_ERR_UNSUPPORTED;
   }
   if (rc == -3) {
