@@ -503,9 +503,14 @@ static int32_t index_create_impl(const uint8_t* text, uint64_t n, const thm_ref*
       return THM_OK;
     }
     // on the GPU where there is one (sa_gpu.hip: seconds against minutes); the host builder otherwise
-    if (n >= (4u << 20) && !getenv("THM_SA_HOST") && build_suffix_array_gpu(text, n, dst.data(), (int)sizeof(C)) == 0) {
-      sa_on_gpu = true;
-      return THM_OK;
+    if (n >= (4u << 20) && !getenv("THM_SA_HOST")) {
+      const int grc = build_suffix_array_gpu(text, n, dst.data(), (int)sizeof(C));
+      if (grc == 0) {
+        sa_on_gpu = true;
+        return THM_OK;
+      }
+      // -1 no device, -2 entries too narrow, -3 not enough free device memory, -4 HIP error (an allocation, mostly)
+      if (getenv("THM_INDEX_TIMING")) fprintf(stderr, "thm_index_create: device suffix sort declined (%d): sorting on the host\n", grc);
     }
     if (sizeof(C) == 4) return build_suffix_array(text, n, (uint32_t*)dst.data()) == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
     return build_suffix_array64(text, n, (uint64_t*)dst.data()) == 0 ? THM_OK : THM_ERR_UNSUPPORTED;
