@@ -20,6 +20,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <utility>
 
 #include "thermite_internal.h"
 
@@ -121,10 +122,11 @@ struct DeviceArrays {  // freed whatever way the builder leaves
 
 }  // namespace
 
-// the wide builder: 64-bit entries out, 41 bytes of device memory per symbol
+// the wide builder: 64-bit entries out, 41 bytes of device memory per symbol (four work arrays and the ranks; the sorts
+// ping-pong between the work arrays -- hipcub::DoubleBuffer -- instead of taking a copy of keys and values as scratch)
 static int build_suffix_array_gpu_wide(const uint8_t* text, uint64_t n, uint64_t* out) {
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 42 + (512u << 20)) return -3;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 42 + (1024u << 20)) return -3;
 #define SA_CK(x)                    \
   do {                              \
     if ((x) != hipSuccess) {        \
@@ -134,14 +136,12 @@ static int build_suffix_array_gpu_wide(const uint8_t* text, uint64_t n, uint64_t
   } while (0)
   DeviceArrays mem;
   uint8_t* d_text = nullptr;
-  uint64_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *rank_at = nullptr;
+  uint64_t* w[4] = {nullptr, nullptr, nullptr, nullptr};  // work arrays: their roles change from step to step
+  uint64_t* rank_at = nullptr;
   unsigned long long* d_distinct = nullptr;
   void* tmp = nullptr;
   SA_CK(mem.alloc(&d_text, n + 8));
-  SA_CK(mem.alloc(&k0, n * 8));
-  SA_CK(mem.alloc(&k1, n * 8));
-  SA_CK(mem.alloc(&v0, n * 8));
-  SA_CK(mem.alloc(&v1, n * 8));
+  for (int i = 0; i < 4; i++) SA_CK(mem.alloc(&w[i], n * 8));
   SA_CK(mem.alloc(&rank_at, n * 8));
   SA_CK(mem.alloc(&d_distinct, 8));
   SA_CK(hipMemcpy(d_text, text, n, hipMemcpyHostToDevice));
@@ -149,8 +149,11 @@ static int build_suffix_array_gpu_wide(const uint8_t* text, uint64_t n, uint64_t
   while (rank_bits < 64 && (n >> rank_bits) != 0) rank_bits++;
   rank_bits++;  // (ranks go up to n - 1, second components up to n)
   size_t sort_bytes = 0, scan_bytes = 0;
-  SA_CK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k0, k1, v0, v1, n, 0, 64));
-  SA_CK(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, k0, v0, hipcub::Max(), n));
+  {
+    hipcub::DoubleBuffer<uint64_t> dk(w[0], w[1]), dv(w[2], w[3]);
+    SA_CK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, n, 0, 64));
+  }
+  SA_CK(hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, w[0], w[1], hipcub::Max(), n));
   const size_t tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
   SA_CK(mem.alloc((uint8_t**)&tmp, tmp_bytes));
   const dim3 grid(256 * 16), block(256);
@@ -160,34 +163,46 @@ static int build_suffix_array_gpu_wide(const uint8_t* text, uint64_t n, uint64_t
     hipLaunchKernelGGL(saw_group_heads, grid, block, 0, 0, a, b, n, head, d_distinct);
     return hipMemcpy(&distinct, d_distinct, 8, hipMemcpyDeviceToHost);
   };
+  // sort (keys in ka, values in va) with kb / vb as the other halves of the buffers: afterwards ka / va hold the result
+  auto sort_pairs = [&](uint64_t*& ka, uint64_t*& kb, uint64_t*& va, uint64_t*& vb, int bits) -> hipError_t {
+    hipcub::DoubleBuffer<uint64_t> dk(ka, kb), dv(va, vb);
+    size_t sb = tmp_bytes;
+    const hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, sb, dk, dv, n, 0, bits);
+    ka = dk.Current();
+    kb = dk.Alternate();
+    va = dv.Current();
+    vb = dv.Alternate();
+    return e;
+  };
   // round 0: by the first 8 bytes
-  hipLaunchKernelGGL(saw_first_keys, grid, block, 0, 0, d_text, n, k0, v0);
-  size_t sb = tmp_bytes;
-  SA_CK(hipcub::DeviceRadixSort::SortPairs(tmp, sb, k0, k1, v0, v1, n, 0, 64));
-  uint64_t* pos = v1;  // positions in the current order
+  uint64_t *ka = w[0], *kb = w[1], *va = w[2], *vb = w[3];
+  hipLaunchKernelGGL(saw_first_keys, grid, block, 0, 0, d_text, n, ka, va);
+  SA_CK(sort_pairs(ka, kb, va, vb, 64));
+  uint64_t* pos = va;    // positions in the current order
+  uint64_t* heads = kb;  // group heads of the current order
   unsigned long long distinct = 0;
-  SA_CK(distinct_after(k1, nullptr, k0, distinct));  // heads -> k0
+  SA_CK(distinct_after(ka, nullptr, heads, distinct));
   for (uint64_t h = 8; distinct != n; h *= 2) {
     if (h >= n) return -5;
-    // ranks of the current order (max-scan of the heads in k0), scattered to text order
-    uint64_t* rs = pos == v1 ? v0 : v1;
-    sb = tmp_bytes;
-    SA_CK(hipcub::DeviceScan::InclusiveScan(tmp, sb, k0, rs, hipcub::Max(), n));
+    // ranks of the current order (max-scan of the heads), scattered to text order; after that only rank_at counts
+    uint64_t* rs = vb;
+    size_t sb = tmp_bytes;
+    SA_CK(hipcub::DeviceScan::InclusiveScan(tmp, sb, heads, rs, hipcub::Max(), n));
     hipLaunchKernelGGL(saw_scatter_ranks, grid, block, 0, 0, pos, rs, n, rank_at);
     // A: by the second component, from text order
-    hipLaunchKernelGGL(saw_second_keys, grid, block, 0, 0, rank_at, (const uint64_t*)nullptr, n, h, k0, v0);
-    sb = tmp_bytes;
-    SA_CK(hipcub::DeviceRadixSort::SortPairs(tmp, sb, k0, k1, v0, v1, n, 0, rank_bits));  // -> k1 (second), v1 (positions)
-    // B: stable, by the first component
-    hipLaunchKernelGGL(saw_first_of, grid, block, 0, 0, rank_at, v1, n, k0);
-    sb = tmp_bytes;
-    SA_CK(hipcub::DeviceRadixSort::SortPairs(tmp, sb, k0, k1, v1, v0, n, 0, rank_bits));  // -> k1 (first), v0 (positions)
-    pos = v0;
-    // groups of equal (first, second): the second components once more, in the new order (-> k0), heads -> v1
-    hipLaunchKernelGGL(saw_second_keys, grid, block, 0, 0, rank_at, pos, n, h, k0, (uint64_t*)nullptr);
-    SA_CK(distinct_after(k1, k0, v1, distinct));
-    // (the heads go where the loop expects them)
-    SA_CK(hipMemcpyAsync(k0, v1, n * 8, hipMemcpyDeviceToDevice, 0));
+    hipLaunchKernelGGL(saw_second_keys, grid, block, 0, 0, rank_at, (const uint64_t*)nullptr, n, h, ka, va);
+    SA_CK(sort_pairs(ka, kb, va, vb, rank_bits));  // ka: second components in order, va: their positions
+    // B: stable, by the first component (the sorted second components are not needed any more: kb takes the keys)
+    hipLaunchKernelGGL(saw_first_of, grid, block, 0, 0, rank_at, va, n, kb);
+    std::swap(ka, kb);
+    SA_CK(sort_pairs(ka, kb, va, vb, rank_bits));  // ka: first components in order, va: positions
+    pos = va;
+    // groups of equal (first, second): the second components once more, in the new order (-> kb), heads -> vb
+    hipLaunchKernelGGL(saw_second_keys, grid, block, 0, 0, rank_at, pos, n, h, kb, (uint64_t*)nullptr);
+    SA_CK(distinct_after(ka, kb, vb, distinct));
+    // roles for the next round: heads in vb, positions in va; ka and kb are free (the scan writes into one of them)
+    heads = vb;
+    std::swap(kb, vb);  // now heads == kb, and vb (the old kb) is free for the scan's output
   }
   SA_CK(hipMemcpy(out, pos, n * 8, hipMemcpyDeviceToHost));
   SA_CK(hipDeviceSynchronize());
